@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests: golden loading, generators, comparison bars."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+
+# seeded generators: loaded by path so CPU-only tests do not need the GPU package to import
+_spec = importlib.util.spec_from_file_location("lpx_problems", os.path.join(ROOT, "linear-programming_amd", "problems.py"))
+gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gen)
+
+GENERATORS = {"gen_primal": gen.gen_primal, "gen_dual": gen.gen_dual, "gen_box": gen.gen_box}
+
+# north_star: objective and solution within 1e-9 relative in fp64
+RTOL = 1e-9
+
+
+def load(name):
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return json.load(f)["cases"]
+
+
+def case_id(cs):
+    if "problem" in cs:
+        return f"{cs['problem']}-{cs['solver']}"
+    return f"{cs['gen']}-{cs['solver']}-m{cs['m']}-n{cs['n']}-s{cs['seed']}-k{cs.get('maxiters', 0)}"
+
+
+def problem_of(cs):
+    """(c, A, b, basis) of a base-solver golden case."""
+    if "gen" in cs:
+        if cs["gen"] == "gen_primal_negG":
+            c, A, b, basis = gen.gen_primal(cs["m"], cs["n"], cs["seed"])
+            A[:, : cs["n"] - cs["m"]] *= -1
+            return c, A, b, basis
+        return GENERATORS[cs["gen"]](cs["m"], cs["n"], cs["seed"])
+    return np.array(cs["c"]), np.array(cs["A"]), np.array(cs["b"]), np.array(cs["basis"])
+
+
+def ub_of(cs):
+    return np.array([np.inf if v == "inf" else v for v in cs["ub"]], dtype=float)
+
+
+def assert_close(got, want, what=""):
+    got = np.asarray(got, dtype=float)
+    want = np.asarray(want, dtype=float)
+    scale = np.maximum(1.0, np.abs(want))
+    err = np.max(np.abs(got - want) / scale) if got.size else 0.0
+    assert err <= RTOL, f"{what}: relative error {err:.3e} > {RTOL}"

@@ -1,0 +1,293 @@
+"""Generate golden vectors by importing the reference (agmuth/linear-programming) in the build container.
+
+Run from the repo root, CPU only:
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--large]
+
+Writes tests/golden/*.json.  A fixture holds DATA only: the generator id + seed (or the literal small
+textbook inputs that the reference's tests/problems.py holds), and the reference's outputs -- pivot triples
+(row, entering column, leaving variable), final basis, x, cost, iters, optimum / exception name.  The
+reference itself (source or bytecode) is never copied; nothing under tests/ reads /root/reference at test time.
+
+Pivot triples are captured by wrapping ``_update_basis`` (non-invasive monkey-patch).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+
+# load the build's own seeded generators without importing the (GPU-only) package __init__
+_spec = importlib.util.spec_from_file_location("lpx_problems", os.path.join(ROOT, "linear-programming_amd", "problems.py"))
+gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gen)
+
+from linprog import primal_solvers, dual_solvers, special_solvers, simplex  # noqa: E402
+from tests import problems as ref_problems  # noqa: E402  (reference's tests/problems.py: data only)
+
+
+class Trace:
+    """Records (row, entering, leaving var) for every _update_basis call of any solver instance."""
+
+    def __init__(self):
+        self.events = []
+        self._orig = primal_solvers.PrimalNaiveSimplexSolver._update_basis
+
+    def __enter__(self):
+        tr = self
+
+        def wrapped(self_, row, col):
+            tr.events.append([int(row), int(col), int(self_.basis[row])])
+            return tr._orig(self_, row, col)
+
+        primal_solvers.PrimalNaiveSimplexSolver._update_basis = wrapped
+        return self
+
+    def __exit__(self, *a):
+        primal_solvers.PrimalNaiveSimplexSolver._update_basis = self._orig
+
+
+def _res(res, events, exc=None):
+    out = {"pivots": events, "exception": exc}
+    if res is not None:
+        out.update(
+            x=[float(v) for v in res.x],
+            basis=None if res.basis is None else [int(v) for v in res.basis],
+            cost=float(res.cost),
+            iters=int(res.iters),
+            optimum=None if res.optimum is None else bool(res.optimum),
+        )
+    return out
+
+
+def run_base(cls, c, A, b, basis, maxiters):
+    with Trace() as tr:
+        try:
+            s = cls(c, A, b, basis)
+        except Exception as e:  # constructor feasibility errors
+            return _res(None, [], type(e).__name__)
+        try:
+            res = s.solve(maxiters)
+        except Exception as e:
+            return _res(None, tr.events, type(e).__name__)
+    return _res(res, tr.events)
+
+
+def lst(a):
+    return None if a is None else np.asarray(a).tolist()
+
+
+def textbook_cases():
+    out = []
+    base = {
+        "PrimalNaiveSimplexSolver": primal_solvers.PrimalNaiveSimplexSolver,
+        "PrimalRevisedSimplexSolver": primal_solvers.PrimalRevisedSimplexSolver,
+    }
+    for name in [k for k in vars(ref_problems) if k.startswith("primal_standard_form_lpp")]:
+        p = getattr(ref_problems, name)
+        for sn, cls in base.items():
+            out.append(dict(problem=name, solver=sn, c=lst(p.c), A=lst(p.A), b=lst(p.b), basis=lst(p.starting_basis),
+                            optimal_bfs=lst(p.optimal_bfs), optimal_basis=lst(p.optimal_basis), maxiters=100,
+                            ref=run_base(cls, p.c, p.A, p.b, p.starting_basis, 100)))
+    p = ref_problems.primal_solver_blands_sequence_problem1
+    for sn, cls in base.items():
+        out.append(dict(problem="primal_solver_blands_sequence_problem1", solver=sn, c=lst(p.c), A=lst(p.A), b=lst(p.b),
+                        basis=lst(p.basis_seq[0]), basis_seq=lst(p.basis_seq), maxiters=100,
+                        ref=run_base(cls, p.c, p.A, p.b, p.basis_seq[0], 100)))
+    dual = {
+        "DualNaiveSimplexSolver": dual_solvers.DualNaiveSimplexSolver,
+        "DualRevisedSimplexSolver": dual_solvers.DualRevisedSimplexSolver,
+    }
+    for name in [k for k in vars(ref_problems) if k.startswith("dual_standard_form_lpp")]:
+        p = getattr(ref_problems, name)
+        for sn, cls in dual.items():
+            out.append(dict(problem=name, solver=sn, c=lst(p.c), A=lst(p.A), b=lst(p.b), basis=lst(p.starting_basis),
+                            optimal_bfs=lst(p.optimal_bfs), optimal_basis=lst(p.optimal_basis), maxiters=100,
+                            ref=run_base(cls, p.c, p.A, p.b, p.starting_basis, 100)))
+    # primal-dual algorithm (inner restricted-primal pivots are traced too)
+    for name in [k for k in vars(ref_problems) if k.startswith("primal_dual_test_problem")]:
+        p = getattr(ref_problems, name)
+        with Trace() as tr:
+            res = special_solvers.PrimalDualAlgorithm(p.c, p.A, p.b).solve()
+        out.append(dict(problem=name, solver="PrimalDualAlgorithm", c=lst(p.c), A=lst(p.A), b=lst(p.b),
+                        optimal_bfs=lst(p.optimal_bfs), ref=_res(res, tr.events)))
+    # general two-phase driver on the primal problems + the infeasible LP of tests/test_general_solvers.py:37-49
+    for name in [k for k in vars(ref_problems) if k.startswith("primal_standard_form_lpp")]:
+        p = getattr(ref_problems, name)
+        with Trace() as tr:
+            res = simplex.SimplexSolver(p.c, p.A, p.b).solve()
+        out.append(dict(problem=name, solver="SimplexSolver", c=lst(p.c), A=lst(p.A), b=lst(p.b),
+                        optimal_bfs=lst(p.optimal_bfs), optimal_basis=lst(p.optimal_basis), ref=_res(res, tr.events)))
+    c = np.array([1, 1, 1, 0, 0, 0, 0, 0])
+    A = np.array([[1, 0, 0, 3, 2, 1, 0, 0], [0, 1, 0, 5, 1, 1, 1, 0], [0, 0, 1, 2, 5, 1, 0, 1], [0, 0, 0, 1, 1, 1, 0, 0]])
+    b = np.array([1, 3, 4, -1])
+    with Trace() as tr:
+        try:
+            simplex.SimplexSolver(c, A, b).solve()
+            r = _res(None, tr.events, None)
+        except Exception as e:
+            r = _res(None, tr.events, type(e).__name__)
+    out.append(dict(problem="infeasible_general", solver="SimplexSolver", c=lst(c), A=lst(A), b=lst(b), ref=r))
+    # bounded-variable primal simplex, Bazaraa ex. 5.6 (tests/test_simplex_with_bounded_variables.py:9-16)
+    c = np.array([-2, -4, -1, 0, 0]); b = np.array([10, 4])
+    A = np.array([[2, 1, 1, 1, 0], [1, 1, -1, -0, 1]])
+    lb = np.array([0, 0, 1, 0, 0]); ub = np.array([4, 6, 4, np.inf, np.inf])
+    out.append(dict(problem="bazaraa_5_6", solver="BoundedVariablePrimalSimplexSolver", c=lst(c), A=lst(A), b=lst(b),
+                    lb=lst(lb), ub=[4, 6, 4, "inf", "inf"], basis=[3, 4], lb_nonbasic=[0, 1, 2], ub_nonbasic=[],
+                    ref=run_bounded(c, A, b, lb, ub, [3, 4], [0, 1, 2], [], 100)))
+    return out
+
+
+def run_bounded(c, A, b, lb, ub, basis, lbn, ubn, maxiters):
+    """Per-iteration trace by repeated solve(maxiters=1) on one object (state persists between calls)."""
+    s = special_solvers.BoundedVariablePrimalSimplexSolver(c, A, b, lb, ub, np.array(basis), np.array(lbn), np.array(ubn))
+    steps = []  # one event per iteration: [row, entering, leaving var, leaving goes to ub?] or [-1, flipped var, -1, now at ub?]
+    res = None
+    try:
+        for _ in range(maxiters):
+            basis0 = s.basis.copy()
+            ub0 = set(int(v) for v in s.ub_nonbasic_vars)
+            res = s.solve(maxiters=1)
+            ub1 = set(int(v) for v in s.ub_nonbasic_vars)
+            if res.optimum:
+                break
+            ch = np.flatnonzero(basis0 != s.basis)
+            if ch.size:
+                r = int(ch[0])
+                steps.append([r, int(s.basis[r]), int(basis0[r]), int(int(basis0[r]) in ub1)])
+            else:
+                (j,) = ub0 ^ ub1
+                steps.append([-1, int(j), -1, int(j in ub1)])
+    except Exception as e:
+        return dict(steps=steps, exception=type(e).__name__)
+    out = _res(res, [])
+    out["steps"] = steps
+    out["iters_total"] = len(steps) + 1
+    out["ub_nonbasic_final"] = sorted(int(v) for v in s.ub_nonbasic_vars)
+    out["lb_nonbasic_final"] = sorted(int(v) for v in s.lb_nonbasic_vars)
+    out["ub_final"] = [float(v) if np.isfinite(v) else "inf" for v in s.ub]
+    return out
+
+
+def diet_case():
+    """examples/diet.py (config 1): literal inputs transcribed from the example's data tables."""
+    spec = importlib.util.spec_from_file_location("ref_diet", "/root/reference/examples/diet.py")
+    # the example is a script (solves at import); capture its solver inputs and result by running it
+    import io
+    import contextlib
+    mod = importlib.util.module_from_spec(spec)
+    buf = io.StringIO()
+    with Trace() as tr, contextlib.redirect_stdout(buf):
+        spec.loader.exec_module(mod)
+    names = {k: v for k, v in vars(mod).items() if isinstance(v, np.ndarray)}
+    res = [v for v in vars(mod).values() if type(v).__name__ == "LinProgResult"][0]
+    return dict(problem="diet", solver="SimplexSolver", arrays={k: lst(v) for k, v in names.items()},
+                ref=_res(res, tr.events), stdout=buf.getvalue())
+
+
+def random_cases(large):
+    out = []
+    PR, DR = primal_solvers.PrimalRevisedSimplexSolver, dual_solvers.DualRevisedSimplexSolver
+    PN, DN = primal_solvers.PrimalNaiveSimplexSolver, dual_solvers.DualNaiveSimplexSolver
+
+    def add(kind, solver, cls, g, m, n, seed, maxiters, keep_x=True):
+        t0 = time.time()
+        c, A, b, basis = g(m, n, seed)
+        r = run_base(cls, c, A, b, basis, maxiters)
+        if not keep_x:
+            r.pop("x", None)
+        out.append(dict(gen=kind, solver=solver, m=m, n=n, seed=seed, maxiters=maxiters, ref=r))
+        print(f"  {solver} {kind} m={m} seed={seed}: {len(r['pivots'])} pivots, {time.time() - t0:.1f}s", flush=True)
+
+    for m in (4, 8, 16, 32):
+        for seed in range(4):
+            add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, m, 2 * m, seed, 100000)
+    for seed in range(8):
+        add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 64, 128, seed, 100000)
+    add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 128, 256, 0, 100000)
+    add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 48, 160, 3, 100000)   # n != 2m
+    add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 64, 128, 0, 50)       # maxiters hit: optimum False
+    for m in (8, 32):
+        for seed in range(2):
+            add("gen_primal", "PrimalNaiveSimplexSolver", PN, gen.gen_primal, m, 2 * m, seed, 100000)
+    for m in (4, 8, 16, 32, 64):
+        for seed in range(3):
+            add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, m, 2 * m, seed, 100000)
+    add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, 128, 256, 0, 100000)
+    add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, 64, 128, 0, 20)             # optimum None
+    for seed in range(2):
+        add("gen_dual", "DualNaiveSimplexSolver", DN, gen.gen_dual, 16, 32, seed, 100000)
+    # constructor errors: primal-infeasible / dual-infeasible starting basis
+    add("gen_dual", "PrimalRevisedSimplexSolver", PR, gen.gen_dual, 8, 16, 0, 100)
+    add("gen_primal", "DualRevisedSimplexSolver", DR, gen.gen_primal, 8, 16, 0, 100)
+    # unbounded: flip the sign of G so that the entering direction has no positive entry
+    c, A, b, basis = gen.gen_primal(8, 16, 0)
+    A[:, :8] *= -1
+    out.append(dict(gen="gen_primal_negG", solver="PrimalRevisedSimplexSolver", m=8, n=16, seed=0, maxiters=100,
+                    ref=run_base(PR, c, A, b, basis, 100)))
+    if large:
+        add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 256, 512, 0, 100000, keep_x=False)
+        add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 1000, 2000, 0, 400, keep_x=False)
+        add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 2000, 4000, 0, 60, keep_x=False)
+    return out
+
+
+def bounded_cases():
+    out = []
+    for m in (16, 64, 128, 170):
+        for seed in range(2 if m < 170 else 1):
+            t0 = time.time()
+            c, A, b, lb, ub, basis, lbn, ubn = gen.gen_box(m, 2 * m, seed)
+            r = run_bounded(c, A, b, lb, ub, basis, lbn, ubn, 100000)
+            out.append(dict(gen="gen_box", solver="BoundedVariablePrimalSimplexSolver", m=m, n=2 * m, seed=seed, ref=r))
+            print(f"  bounded m={m} seed={seed}: {r.get('iters_total')} iters, {time.time() - t0:.1f}s", flush=True)
+    return out
+
+
+def primal_dual_cases():
+    out = []
+    for m in (4, 8, 16, 32):
+        for seed in range(2):
+            t0 = time.time()
+            c, A, b, _ = gen.gen_dual(m, 2 * m, seed)
+            with Trace() as tr:
+                try:
+                    res = special_solvers.PrimalDualAlgorithm(c, A, b).solve(100000, 100000)
+                    r = _res(res, tr.events)
+                except Exception as e:
+                    r = _res(None, tr.events, type(e).__name__)
+            out.append(dict(gen="gen_dual", solver="PrimalDualAlgorithm", m=m, n=2 * m, seed=seed, ref=r))
+            print(f"  primal-dual m={m} seed={seed}: iters={r.get('iters')} {time.time() - t0:.1f}s", flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--large", action="store_true", help="also m=256 full solve and m=1000/2000 prefixes (minutes)")
+    args = ap.parse_args()
+    meta = dict(numpy=np.__version__, python=sys.version.split()[0],
+                note="generated by importing the reference in the build container; data only")
+
+    def dump(name, cases):
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(dict(meta=meta, cases=cases), f)
+        print("wrote", name, len(cases), "cases", flush=True)
+
+    dump("textbook.json", textbook_cases())
+    dump("diet.json", [diet_case()])
+    dump("bounded.json", bounded_cases())
+    dump("primal_dual.json", primal_dual_cases())
+    dump("random.json", random_cases(False))
+    if args.large:
+        dump("random_large.json", random_cases(True)[-3:])
+
+
+if __name__ == "__main__":
+    main()
