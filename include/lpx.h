@@ -1,0 +1,215 @@
+/*
+ * lpx.h -- C ABI of liblpx.so: the MI355X (gfx950) dense simplex pivot path.
+ *
+ * The reference (agmuth/linear-programming, pure Python + NumPy) has no FFI; its boundary is the Python
+ * solver-class surface.  liblpx is what a maintainer would bind from those classes with ctypes: one entry
+ * point per NumPy call site of the pivot loop.  Every entry point cites the reference function it replaces
+ * (file:line relative to the reference checkout).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, int64 sizes, `void *stream` is a hipStream_t (NULL = default stream);
+ *   - every function returns 0 on success, a negative LPX_E_* code otherwise (never throws, never exits);
+ *     lpx_last_error() returns a message for the calling thread's last failure;
+ *   - the library allocates NO device memory: all buffers, including scratch (`workspace`), are owned by the
+ *     caller (the Python host uses torch tensors); *_workspace_bytes() says how much scratch a problem needs;
+ *   - all calls are asynchronous on `stream` except lpx_read_ctrl (which synchronises the stream);
+ *   - matrices are row-major; leading dimensions are in elements; all base pointers 16-byte aligned and
+ *     leading dimensions multiples of 4 (float) / 2 (double) so that rows stay 16-byte aligned.
+ *   - the solver state lives in HBM across iterations; the only per-iteration host traffic is the optional
+ *     read of the 128-byte control block (lpx_ctrl).
+ */
+#ifndef LPX_H
+#define LPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPX_VERSION 1
+
+/* error codes */
+#define LPX_OK 0
+#define LPX_E_ARG (-1)  /* bad argument (null pointer, misaligned, size mismatch, workspace too small) */
+#define LPX_E_HIP (-2)  /* a HIP runtime call failed */
+#define LPX_E_SIZE (-3) /* problem exceeds a compiled-in limit of the entry point */
+
+/* lpx_ctrl.status: maps 1:1 onto the reference's loop exits / exceptions (linprog/exceptions.py:1-22) */
+#define LPX_RUNNING 0          /* loop not finished (maxiters reached => optimum False/None) */
+#define LPX_OPTIMAL 1          /* primal_solvers.py:195-198, dual_solvers.py:99-102, special_solvers.py:230-233 */
+#define LPX_PRIMAL_UNBOUNDED 2 /* PrimalIsUnboundedError: primal_solvers.py:130-132, special_solvers.py:256-257 */
+#define LPX_DUAL_UNBOUNDED 3   /* DualIsUnboundedError: dual_solvers.py:41-44 */
+#define LPX_NOT_NONBASIC 4     /* ValueError at special_solvers.py:331 */
+
+/* var_state[j] */
+#define LPX_VS_BASIC 0
+#define LPX_VS_LOWER 1    /* nonbasic at its lower bound (every nonbasic variable of the standard-form solvers) */
+#define LPX_VS_UPPER 2    /* nonbasic at its upper bound (bounded-variable solver) */
+#define LPX_VS_EXCLUDED 3 /* column outside the restricted primal (primal-dual algorithm) */
+
+/* lpx_revised_iterate `kind` */
+#define LPX_KIND_PRIMAL 0  /* PrimalRevisedSimplexSolver.solve   primal_solvers.py:176-209 */
+#define LPX_KIND_DUAL 1    /* DualRevisedSimplexSolver.solve     dual_solvers.py:82-108 */
+#define LPX_KIND_BOUNDED 2 /* BoundedVariablePrimalSimplexSolver.solve  special_solvers.py:221-343 */
+
+/* Device-resident control block (128 bytes).  Written only by kernels (and by lpx_ctrl_reset); the host
+ * reads it with lpx_read_ctrl.  `counter` is the reference's self.counter. */
+typedef struct lpx_ctrl {
+    int32_t status;
+    int32_t f32_phase;    /* 1 while B^-1 / x_B still hold float32-computed values */
+    int64_t counter;      /* iterations started in the current solve() call (primal_solvers.py:189-192) */
+    int64_t pivots;       /* state changes since construction; also the write index of the pivot log */
+    int64_t enter_j;      /* entering column of the last iteration */
+    int64_t leave_r;      /* leaving row of the last iteration (-1: bound flip) */
+    int64_t leave_var;    /* variable that left */
+    double price_val;     /* min reduced cost / min x_B / max bounded reduced cost of the last iteration */
+    double ratio_val;     /* min ratio of the last ratio test */
+    double aux_val;       /* max(d) (primal), min(row) (dual) */
+    int32_t flip;         /* bounded: 1 if the last iteration was a bound flip (no basis change) */
+    int32_t leave_state;  /* bounded: LPX_VS_LOWER / LPX_VS_UPPER the leaving variable went to */
+    int64_t reserved[6];
+} lpx_ctrl;
+
+/* State of one LP in revised form (explicit B^-1, primal_solvers.py:13-41).  A host-side struct of DEVICE
+ * pointers, passed by pointer to every call and copied by value into the kernels' arguments. */
+typedef struct lpx_revised {
+    int64_t m, n;       /* rows, columns of A */
+    int64_t ldA;        /* >= n, multiple of 4 */
+    int64_t ldAt;       /* >= m, multiple of 4 */
+    int64_t ldB;        /* >= m, multiple of 2 */
+    const float *A;     /* m x ldA   float32 values (preprocessing.py:8) */
+    const float *At;    /* n x ldAt  transposed copy of A (column j of A contiguous) */
+    const float *b;     /* m */
+    const float *c;     /* n */
+    double *Binv;       /* m x ldB   inv_basis_matrix */
+    double *xB;         /* m         bfs */
+    int64_t *basis;     /* m */
+    int32_t *var_state; /* n */
+    const double *lb;   /* n, bounded solver only (else NULL) */
+    const double *ub;   /* n, bounded solver only (else NULL) */
+    lpx_ctrl *ctrl;
+    int64_t *log;       /* 3*log_cap (row, entering, leaving var) per state change, or NULL */
+    int64_t log_cap;
+    void *workspace;
+    int64_t workspace_bytes;
+} lpx_revised;
+
+/* State of one LP in tableau form: T = [B^-1 A | x_B ; rc | -z], (m+1) x ld, carried and updated in place.
+ * The build's own data layout for the large single-GPU / column-partitioned configs (SURVEY.md Appendix A,
+ * "Tableau equivalent"); the pivot rules are those of primal_solvers.py:135-167.
+ * Column-partitioned: this rank holds global columns [col0, col0+n) and a replica of the x_B column. */
+typedef struct lpx_tableau {
+    int64_t m, n, ld;   /* n = local structural columns; column n of T is x_B; ld >= n+1, multiple of 2 */
+    int64_t col0;       /* global index of local column 0 (0 when unpartitioned) */
+    int64_t n_global;   /* total structural columns over all ranks */
+    double *T;
+    int64_t *basis;     /* m, global column indices (replicated) */
+    int32_t *var_state; /* n (local columns) */
+    lpx_ctrl *ctrl;
+    int64_t *log;
+    int64_t log_cap;
+    void *workspace;
+    int64_t workspace_bytes;
+} lpx_tableau;
+
+/* ---------------------------------------------------------------------------------------------- misc */
+int lpx_version(void);
+const char *lpx_last_error(void);
+/* Zero a control block and set f32_phase (solver construction: primal_solvers.py:37-40). */
+int lpx_ctrl_init(lpx_ctrl *dev_ctrl, int32_t f32_phase, void *stream);
+/* Start of a solve() call: counter = 0, status = RUNNING (primal_solvers.py:189-190, dual_solvers.py:95). */
+int lpx_ctrl_begin_solve(lpx_ctrl *dev_ctrl, void *stream);
+/* Copy the control block to the host and synchronise the stream: the "scalar status flag" round trip. */
+int lpx_read_ctrl(const lpx_ctrl *dev_ctrl, lpx_ctrl *host_ctrl, void *stream);
+
+/* ------------------------------------------------------------------------------ revised-form solver loop */
+int64_t lpx_revised_workspace_bytes(int64_t m, int64_t n);
+
+/* Enqueue `iters` iterations of the solver loop `kind` (no host synchronisation; kernels become no-ops
+ * once ctrl->status != RUNNING).  Replaces the bodies of
+ *   PrimalNaiveSimplexSolver.solve              primal_solvers.py:191-207 (with the revised pivot :255-263),
+ *   DualNaiveSimplexSolver.solve                dual_solvers.py:96-106,
+ *   BoundedVariablePrimalSimplexSolver.solve    special_solvers.py:225-341. */
+int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *stream);
+
+/* PrimalRevisedSimplexSolver.pivot(row, col), primal_solvers.py:255-263 (called from outside the loop by
+ * PhaseOneSimplexSolver, special_solvers.py:77-79). */
+int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream);
+
+/* _get_bfs_expanded + _calc_current_cost, primal_solvers.py:72-79 (bounded: special_solvers.py:201-206):
+ * x[n] = scatter of x_B (plus nonbasic bound values when lb/ub are set); cost[0] = dot(c, x). */
+int lpx_revised_expand(const lpx_revised *s, double *x, double *cost, void *stream);
+
+/* BoundedVariablePrimalSimplexSolver._update_bfs, special_solvers.py:169-175. */
+int lpx_bounded_update_bfs(const lpx_revised *s, void *stream);
+
+/* Reduced costs into rc[n] (primal_solvers.py:59-66; bounded=1: special_solvers.py:177-199). */
+int lpx_revised_reduced_costs(const lpx_revised *s, int bounded, double *rc, void *stream);
+
+/* ----------------------------------------------------------------- primal-dual restricted-problem updates */
+/* special_solvers.py:405-406: v = y @ A ; var_state[j] = LOWER if isclose(v_j, c_j) else EXCLUDED, for the
+ * first n_orig columns (the artificial block behind them stays LOWER).  c64 = float64 costs of the
+ * unrestricted problem. */
+int lpx_pd_admissible(const lpx_revised *s, const double *y, const double *c64, int64_t n_orig, double *v,
+                      void *stream);
+/* special_solvers.py:430-444: y_rp = c_B B^-1 of the solved restricted primal; u = y_rp @ A;
+ * out[0] = theta = min over excluded j with u_j > 0 of (c64_j - v_j)/u_j ; out[1] = max(u_j over admissible j,
+ * y_rp_i) (dual unbounded iff <= 0, :435-436); then y += theta * y_rp unless out[1] <= 0. */
+int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c64, const double *v, int64_t n_orig,
+                     double *out, void *stream);
+
+/* ----------------------------------------------------------------------------- tableau-form solver loop */
+int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
+/* `iters` primal iterations on an unpartitioned tableau (same rules as LPX_KIND_PRIMAL). */
+int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream);
+/* Column-partitioned step, part 1: local pricing over owned columns and candidate pivot column.
+ * sendbuf[0] = local min rc, sendbuf[1] = global index of the first owned column with rc<0 (or 2^62),
+ * sendbuf[2 .. 2+m] = that column of T (m entries + its reduced cost).  Length lpx_tableau_msg_len(m). */
+int64_t lpx_tableau_msg_len(int64_t m);
+int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *stream);
+/* Part 2, after an all-gather of the proposals (recvbuf = nranks consecutive messages): pick the global
+ * entering column (lowest index), run the ratio test on the replicated x_B column, update the local slice. */
+int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);
+/* x[n_global-sized on rank owning..] : x_B and basis are replicated, so every rank can expand: x, cost. */
+int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
+
+/* ------------------------------------------------------------------------------------ batched small LPs */
+/* One workgroup per LP, state resident in LDS (PrimalRevisedSimplexSolver semantics, slack or general start
+ * basis with B^-1 supplied).  Arrays are batch-major.  Limits: m <= 64, n <= 128 (LPX_E_SIZE otherwise). */
+int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                             const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                             int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
+                             void *stream);
+
+/* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
+/* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:
+ * _update_inv_basis_matrix / _update_bfs, primal_solvers.py:247-253.  rowr_scratch: >= cols doubles. */
+int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
+                     double *rowr_scratch, void *stream);
+/* Eta column, primal_solvers.py:235-244: e_i = (-d_i)/d_r, e_r = 1/d_r. */
+int lpx_eta(const double *d, int64_t m, int64_t r, double *e, void *stream);
+/* primal_solvers.py:135-142: out_val[0] = min(rc), out_idx[0] = first j with rc_j<0 (or -1).
+ * var_state may be NULL; EXCLUDED columns are skipped.  scratch: lpx_reduce_scratch_bytes() bytes. */
+int64_t lpx_reduce_scratch_bytes(void);
+int lpx_price_first_negative(const double *rc, const int32_t *var_state, int64_t n, double *out_val,
+                             int64_t *out_idx, void *scratch, void *stream);
+/* special_solvers.py:208-214: max(rc) and first argmax. */
+int lpx_price_argmax(const double *rc, int64_t n, double *out_val, int64_t *out_idx, void *scratch, void *stream);
+/* primal_solvers.py:149-167 + utils.py:5-10; out_val = {theta_min, max(d)}, out_idx = first argmin. */
+int lpx_ratio_primal(const double *x, const double *d, int64_t m, int f32, double *out_val, int64_t *out_idx,
+                     void *scratch, void *stream);
+/* dual_solvers.py:61-80 + utils.py:12-17; out_val = {theta_min, min(row)}, out_idx = first argmin. */
+int lpx_ratio_dual(const double *rc, const double *row, const int32_t *var_state, int64_t n, int f32,
+                   double *out_val, int64_t *out_idx, void *scratch, void *stream);
+/* special_solvers.py:239-329; out_val = {min g1, min g2}, out_idx = {argmin g1, argmin g2}. */
+int lpx_ratio_bounded(const double *x, const double *d, const double *lbB, const double *ubB, int64_t m,
+                      double sign, double *out_val, int64_t *out_idx, void *scratch, void *stream);
+/* dual_solvers.py:47-54: min(x_B), first i with x_i<0. */
+int lpx_dual_row_select(const double *xB, int64_t m, double *out_val, int64_t *out_idx, void *scratch,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPX_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of liblpx.so (include/lpx.h) -- the only route from the Python host to the GPU.
+
+There is no CPU fallback: if the library is missing or no HIP device is visible, every solver constructor
+raises LpxBackendError.  ``python __graft_entry__.py`` (or ``make -C linear-programming_amd/csrc``) builds
+the library in-tree for gfx950.
+"""
+import ctypes as C
+import os
+
+from .exceptions import LpxBackendError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblpx.so")
+
+# status codes (lpx.h)
+RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
+VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
+KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED = 0, 1, 2
+
+vp = C.c_void_p
+i64 = C.c_int64
+
+
+class LpxCtrl(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("f32_phase", C.c_int32),
+        ("counter", i64), ("pivots", i64), ("enter_j", i64), ("leave_r", i64), ("leave_var", i64),
+        ("price_val", C.c_double), ("ratio_val", C.c_double), ("aux_val", C.c_double),
+        ("flip", C.c_int32), ("leave_state", C.c_int32),
+        ("reserved", i64 * 6),
+    ]
+
+
+assert C.sizeof(LpxCtrl) == 128
+
+
+class LpxRevised(C.Structure):
+    _fields_ = [
+        ("m", i64), ("n", i64), ("ldA", i64), ("ldAt", i64), ("ldB", i64),
+        ("A", vp), ("At", vp), ("b", vp), ("c", vp),
+        ("Binv", vp), ("xB", vp), ("basis", vp), ("var_state", vp),
+        ("lb", vp), ("ub", vp), ("ctrl", vp),
+        ("log", vp), ("log_cap", i64),
+        ("workspace", vp), ("workspace_bytes", i64),
+    ]
+
+
+class LpxTableau(C.Structure):
+    _fields_ = [
+        ("m", i64), ("n", i64), ("ld", i64), ("col0", i64), ("n_global", i64),
+        ("T", vp), ("basis", vp), ("var_state", vp), ("ctrl", vp),
+        ("log", vp), ("log_cap", i64),
+        ("workspace", vp), ("workspace_bytes", i64),
+    ]
+
+
+_SIGS = {
+    "lpx_version": (C.c_int, []),
+    "lpx_last_error": (C.c_char_p, []),
+    "lpx_ctrl_init": (C.c_int, [vp, C.c_int32, vp]),
+    "lpx_ctrl_begin_solve": (C.c_int, [vp, vp]),
+    "lpx_read_ctrl": (C.c_int, [vp, C.POINTER(LpxCtrl), vp]),
+    "lpx_revised_workspace_bytes": (i64, [i64, i64]),
+    "lpx_revised_iterate": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
+    "lpx_revised_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),
+    "lpx_revised_expand": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp]),
+    "lpx_bounded_update_bfs": (C.c_int, [C.POINTER(LpxRevised), vp]),
+    "lpx_revised_reduced_costs": (C.c_int, [C.POINTER(LpxRevised), C.c_int, vp, vp]),
+    "lpx_pd_admissible": (C.c_int, [C.POINTER(LpxRevised), vp, vp, i64, vp, vp]),
+    "lpx_pd_dual_step": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp, i64, vp, vp]),
+    "lpx_tableau_workspace_bytes": (i64, [i64, i64]),
+    "lpx_tableau_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
+    "lpx_tableau_msg_len": (i64, [i64]),
+    "lpx_tableau_propose": (C.c_int, [C.POINTER(LpxTableau), vp, vp]),
+    "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
+    "lpx_tableau_expand": (C.c_int, [C.POINTER(LpxTableau), vp, vp, vp, vp]),
+    "lpx_batched_primal_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "lpx_pivot_update": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, vp]),
+    "lpx_eta": (C.c_int, [vp, i64, i64, vp, vp]),
+    "lpx_reduce_scratch_bytes": (i64, []),
+    "lpx_price_first_negative": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),
+    "lpx_price_argmax": (C.c_int, [vp, i64, vp, vp, vp, vp]),
+    "lpx_ratio_primal": (C.c_int, [vp, vp, i64, C.c_int, vp, vp, vp, vp]),
+    "lpx_ratio_dual": (C.c_int, [vp, vp, vp, i64, C.c_int, vp, vp, vp, vp]),
+    "lpx_ratio_bounded": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, vp, vp, vp, vp]),
+    "lpx_dual_row_select": (C.c_int, [vp, i64, vp, vp, vp, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load liblpx.so once; raise LpxBackendError (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LpxBackendError(
+                f"{LIB_PATH} not found: build it with `make -C linear-programming_amd/csrc` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise LpxBackendError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().lpx_last_error()
+        raise LpxBackendError(f"liblpx error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,1175 @@
+// lpx_core.hip -- revised-form simplex loop on MI355X (gfx950): pricing, direction, ratio tests,
+// eta/prepare, rank-1 update, expansion; plus the individually exported kernels and control-block helpers.
+//
+// One iteration is a short chain of kernels on one stream; scalars that one stage produces for the next
+// (entering column, leaving row, status) travel through the device-resident control block and through
+// per-workgroup partial arrays that the next kernel combines in its prologue, so there is NO host round trip
+// inside the loop.  A kernel never reads a control field that the same kernel writes, except `status`,
+// whose only transitions are RUNNING -> terminal and are recomputed identically by every workgroup.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lpx_device.hpp"
+#include "lpx_rank1.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// error string (thread local)
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void lpx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *lpx_last_error(void) { return g_err; }
+extern "C" int lpx_version(void) { return LPX_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------------
+// workspace layout (pure function of m, n)
+// ---------------------------------------------------------------------------------------------------------
+struct ColsumPlan {
+    int64_t nstrips, nch, rpc;
+};
+// V = columns per lane (16-byte vector): 2 for fp64 matrices, 4 for fp32
+static inline ColsumPlan colsum_plan(int64_t rows, int64_t cols, int V)
+{
+    ColsumPlan p;
+    p.nstrips = lpx_cdiv(cols, (int64_t)LPX_BLOCK * V);
+    int64_t nch = lpx_cdiv(1024, p.nstrips);
+    if (nch > 256) nch = 256;
+    if (nch < 1) nch = 1;
+    p.rpc = lpx_cdiv(rows, nch);
+    if (p.rpc < 4) p.rpc = 4;
+    p.nch = lpx_cdiv(rows, p.rpc);
+    return p;
+}
+
+struct RevisedWs {
+    ColsumPlan py, pa;
+    int64_t ldyp, ldzp;
+    double *ypart, *y, *zpart, *zpart2, *rc, *row, *d, *e, *rowr, *w, *scal;
+    lpx_ctrl *scr_ctrl; // scratch control block for the primal-dual steps
+    Partials price, ratio;
+    int64_t bytes;
+};
+static inline char *carve(char *&p, int64_t bytes)
+{
+    char *q = p;
+    p += lpx_roundup(bytes, 256);
+    return q;
+}
+static inline void carve_partials(char *&p, Partials &P)
+{
+    P.v0 = (double *)carve(p, 8 * LPX_MAXP);
+    P.i0 = (int64_t *)carve(p, 8 * LPX_MAXP);
+    P.v1 = (double *)carve(p, 8 * LPX_MAXP);
+    P.i1 = (int64_t *)carve(p, 8 * LPX_MAXP);
+}
+static RevisedWs revised_ws(int64_t m, int64_t n, void *base)
+{
+    RevisedWs w;
+    w.py = colsum_plan(m, m, 2);
+    w.pa = colsum_plan(m, n, 4);
+    w.ldyp = lpx_roundup(m, 2);
+    w.ldzp = lpx_roundup(n, 4);
+    char *p = (char *)base;
+    w.ypart = (double *)carve(p, 8 * w.py.nch * w.ldyp);
+    w.y = (double *)carve(p, 8 * w.ldyp);
+    w.zpart = (double *)carve(p, 8 * w.pa.nch * w.ldzp);
+    w.zpart2 = (double *)carve(p, 8 * w.pa.nch * w.ldzp);
+    w.rc = (double *)carve(p, 8 * w.ldzp);
+    w.row = (double *)carve(p, 8 * w.ldzp);
+    w.d = (double *)carve(p, 8 * (m + 2));
+    w.e = (double *)carve(p, 8 * (m + 2));
+    w.rowr = (double *)carve(p, 8 * (lpx_roundup(m, 2) + 2));
+    w.w = (double *)carve(p, 8 * (m + 2));
+    w.scal = (double *)carve(p, 8 * 16);
+    w.scr_ctrl = (lpx_ctrl *)carve(p, sizeof(lpx_ctrl));
+    carve_partials(p, w.price);
+    carve_partials(p, w.ratio);
+    w.bytes = (int64_t)(p - (char *)base);
+    return w;
+}
+extern "C" int64_t lpx_revised_workspace_bytes(int64_t m, int64_t n)
+{
+    if (m <= 0 || n <= 0) return 0;
+    return revised_ws(m, n, nullptr).bytes;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// control block helpers
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_ctrl_init(lpx_ctrl *c, int32_t f32_phase)
+{
+    lpx_ctrl z;
+    memset(&z, 0, sizeof z);
+    z.f32_phase = f32_phase;
+    z.enter_j = -1;
+    z.leave_r = -1;
+    z.leave_var = -1;
+    *c = z;
+}
+__global__ void k_ctrl_begin(lpx_ctrl *c)
+{
+    c->counter = 0;
+    c->status = LPX_RUNNING;
+    c->flip = 0;
+}
+extern "C" int lpx_ctrl_init(lpx_ctrl *dev_ctrl, int32_t f32_phase, void *stream)
+{
+    LPX_REQUIRE(dev_ctrl != nullptr, "null control block");
+    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_ctrl, f32_phase);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_ctrl_begin_solve(lpx_ctrl *dev_ctrl, void *stream)
+{
+    LPX_REQUIRE(dev_ctrl != nullptr, "null control block");
+    hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_ctrl);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_read_ctrl(const lpx_ctrl *dev_ctrl, lpx_ctrl *host_ctrl, void *stream)
+{
+    LPX_REQUIRE(dev_ctrl != nullptr && host_ctrl != nullptr, "null control block");
+    LPX_HIP(hipMemcpyAsync(host_ctrl, dev_ctrl, sizeof(lpx_ctrl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    LPX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2a: column sums  part[chunk][k] = sum_{i in chunk} w_i * M[i][k]      (y = c_B B^-1 ; z = y A ; row = B^-1[r,:] A)
+// primal_solvers.py:64 evaluates  c[basis] @ inv_basis_matrix @ A  left to right; dual_solvers.py:37-39.
+// HBM-bound: M is read once (8 m^2 B for B^-1, 4 m n B for the float32 A).
+// ---------------------------------------------------------------------------------------------------------
+enum { W_CB = 0, W_VEC = 1, W_BINV_ROW = 2 };
+struct ColsumArgs {
+    const void *M;
+    int64_t ld, rows, cols, rpc;
+    int wmode;
+    const float *c;
+    const int64_t *basis;
+    const double *wvec;
+    const double *Binv;
+    int64_t ldB;
+    double *part;
+    int64_t ldp;
+    const lpx_ctrl *ctrl;
+};
+
+template <typename AccT>
+__device__ __forceinline__ AccT colsum_weight(const ColsumArgs &a, int64_t i, int64_t r)
+{
+    if (a.wmode == W_CB) return (AccT)a.c[a.basis[i]];
+    if (a.wmode == W_VEC) return (AccT)a.wvec[i];
+    return (AccT)a.Binv[r * a.ldB + i];
+}
+
+template <typename MatT, typename AccT, int V>
+__device__ __forceinline__ void colsum_body(const ColsumArgs &a)
+{
+    typedef MatT vec_t __attribute__((ext_vector_type(V)));
+    const int64_t col = ((int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x) * V;
+    if (col >= a.cols) return;
+    const int64_t row0 = (int64_t)blockIdx.y * a.rpc;
+    const int64_t row1 = (row0 + a.rpc < a.rows) ? row0 + a.rpc : a.rows;
+    const int64_t r = (a.wmode == W_BINV_ROW) ? a.ctrl->leave_r : 0;
+    AccT acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = (AccT)0;
+    const MatT *p = (const MatT *)a.M + row0 * a.ld + col;
+    int64_t i = row0;
+    for (; i + 4 <= row1; i += 4) {
+        const vec_t x0 = *(const vec_t *)p;
+        const vec_t x1 = *(const vec_t *)(p + a.ld);
+        const vec_t x2 = *(const vec_t *)(p + 2 * a.ld);
+        const vec_t x3 = *(const vec_t *)(p + 3 * a.ld);
+        const AccT w0 = colsum_weight<AccT>(a, i, r), w1 = colsum_weight<AccT>(a, i + 1, r);
+        const AccT w2 = colsum_weight<AccT>(a, i + 2, r), w3 = colsum_weight<AccT>(a, i + 3, r);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            acc[v] = fma(w0, (AccT)x0[v], acc[v]);
+            acc[v] = fma(w1, (AccT)x1[v], acc[v]);
+            acc[v] = fma(w2, (AccT)x2[v], acc[v]);
+            acc[v] = fma(w3, (AccT)x3[v], acc[v]);
+        }
+        p += 4 * a.ld;
+    }
+    for (; i < row1; ++i) {
+        const vec_t x0 = *(const vec_t *)p;
+        const AccT w0 = colsum_weight<AccT>(a, i, r);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = fma(w0, (AccT)x0[v], acc[v]);
+        p += a.ld;
+    }
+    double *out = a.part + (int64_t)blockIdx.y * a.ldp + col;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (col + v < a.cols) out[v] = (double)acc[v];
+}
+
+template <typename MatT, int V>
+__global__ __launch_bounds__(LPX_BLOCK) void k_colsum(ColsumArgs a)
+{
+    if (a.ctrl->status != LPX_RUNNING) return;
+    if (a.ctrl->f32_phase) colsum_body<MatT, float, V>(a);
+    else colsum_body<MatT, double, V>(a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2b/K3: finish the column sums (fixed chunk order) and apply the stage's epilogue + workgroup partial reduce
+//   FIN_Y       y_k                                                        primal_solvers.py:64 (first product)
+//   FIN_PRIMAL  rc_j = c_j - z_j ; rc[basis] = 0 ; (min rc, first j: rc_j<0)   :64-66, :135-142
+//   FIN_BOUNDED rc_j = +-fl32(-c_j + z_j) ; (max rc, first argmax)             special_solvers.py:177-214
+//   FIN_DUAL    rc_j as FIN_PRIMAL, row_j = sum2 ; theta_j = (-rc_j)/row_j ; (min theta, first j), min row
+//                                                                              dual_solvers.py:37-40, :61-80
+// ---------------------------------------------------------------------------------------------------------
+enum { FIN_Y = 0, FIN_PRIMAL = 1, FIN_BOUNDED = 2, FIN_DUAL = 3 };
+struct FinArgs {
+    int mode;
+    int64_t cols, nch, ldp;
+    const double *part;
+    const double *part2;
+    const float *c;
+    const int32_t *var_state;
+    double *out;  // y or rc
+    double *out2; // dual row
+    Partials P;
+    const lpx_ctrl *ctrl;
+};
+
+template <typename AccT>
+__device__ __forceinline__ AccT fin_sum(const double *part, int64_t nch, int64_t ldp, int64_t col)
+{
+    AccT s = (AccT)0;
+    for (int64_t ch = 0; ch < nch; ++ch) s += (AccT)part[ch * ldp + col];
+    return s;
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
+{
+    __shared__ BlockRed red;
+    if (a.ctrl->status != LPX_RUNNING) return;
+    const bool f32 = a.ctrl->f32_phase != 0;
+    const int64_t col = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const bool in = col < a.cols;
+    double s = 0.0, s2 = 0.0;
+    if (in) {
+        s = f32 ? (double)fin_sum<float>(a.part, a.nch, a.ldp, col) : fin_sum<double>(a.part, a.nch, a.ldp, col);
+        if (a.mode == FIN_DUAL)
+            s2 = f32 ? (double)fin_sum<float>(a.part2, a.nch, a.ldp, col) : fin_sum<double>(a.part2, a.nch, a.ldp, col);
+    }
+    if (a.mode == FIN_Y) {
+        if (in) a.out[col] = s;
+        return;
+    }
+    const int32_t vs = in ? a.var_state[col] : LPX_VS_EXCLUDED;
+    const bool live = in && vs != LPX_VS_EXCLUDED;
+    if (a.mode == FIN_PRIMAL || a.mode == FIN_DUAL) {
+        double rc = 0.0;
+        if (live && vs != LPX_VS_BASIC) rc = f32 ? (double)(a.c[col] - (float)s) : (double)a.c[col] - s;
+        if (in) a.out[col] = rc;
+        if (a.mode == FIN_PRIMAL) {
+            const double mn = block_min(live ? rc : LPX_INF, red);
+            const int64_t jn = block_imin((live && rc < 0.0) ? col : LPX_NOIDX, red);
+            if (threadIdx.x == 0) {
+                a.P.v0[blockIdx.x] = mn;
+                a.P.i0[blockIdx.x] = jn;
+            }
+        } else {
+            double row = 0.0;
+            if (live && vs != LPX_VS_BASIC) row = s2;
+            if (in) a.out2[col] = row;
+            VI t{live ? lpx_dsd(rc, row, f32) : LPX_INF, live ? col : LPX_NOIDX};
+            t = block_argmin(t, red);
+            const double rmin = block_min(live ? row : LPX_INF, red);
+            if (threadIdx.x == 0) {
+                a.P.v0[blockIdx.x] = t.v;
+                a.P.i0[blockIdx.x] = t.i;
+                a.P.v1[blockIdx.x] = rmin;
+            }
+        }
+    } else { // FIN_BOUNDED: the reference's reduced-cost array is float32 (special_solvers.py:182-196)
+        double rc = 0.0;
+        if (in && vs != LPX_VS_BASIC) {
+            const float t = f32 ? ((-a.c[col]) + (float)s) : (float)((double)(-a.c[col]) + s);
+            rc = (vs == LPX_VS_UPPER) ? (double)(-t) : (double)t;
+        }
+        if (in) a.out[col] = rc;
+        // first argmax == argmin of (-rc, index)
+        VI t{in ? -rc : LPX_INF, in ? col : LPX_NOIDX};
+        t = block_argmin(t, red);
+        if (threadIdx.x == 0) {
+            a.P.v0[blockIdx.x] = -t.v;
+            a.P.i0[blockIdx.x] = t.i;
+        }
+    }
+}
+
+// combine per-workgroup partials (executed redundantly by every workgroup of the consuming kernel)
+__device__ __forceinline__ VI combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
+{
+    VI b{LPX_INF, LPX_NOIDX};
+    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK)
+        if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
+    return block_argmin(b, red);
+}
+__device__ __forceinline__ double combine_min(const double *v, int64_t np, BlockRed &red)
+{
+    double b = LPX_INF;
+    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmin(b, v[k]);
+    return block_min(b, red);
+}
+__device__ __forceinline__ double combine_max(const double *v, int64_t np, BlockRed &red)
+{
+    double b = -LPX_INF;
+    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmax(b, v[k]);
+    return block_max(b, red);
+}
+__device__ __forceinline__ int64_t combine_imin(const int64_t *i, int64_t np, BlockRed &red)
+{
+    int64_t b = LPX_NOIDX;
+    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = i[k] < b ? i[k] : b;
+    return block_imin(b, red);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5: dual row selection (single workgroup): min(x_B), first i with x_i < 0     dual_solvers.py:47-54, :95-102
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPX_BLOCK) void k_dual_select(const double *xB, int64_t m, lpx_ctrl *ctrl)
+{
+    __shared__ BlockRed red;
+    if (ctrl->status != LPX_RUNNING) return;
+    double mn = LPX_INF;
+    int64_t r = LPX_NOIDX;
+    for (int64_t i = threadIdx.x; i < m; i += LPX_BLOCK) {
+        const double x = xB[i];
+        mn = fmin(mn, x);
+        if (x < 0.0 && i < r) r = i;
+    }
+    mn = block_min(mn, red);
+    r = block_imin(r, red);
+    if (threadIdx.x == 0) {
+        ctrl->counter += 1;
+        ctrl->price_val = mn;
+        if (lpx_is_optimal_min(mn)) ctrl->status = LPX_OPTIMAL;
+        else ctrl->leave_r = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: entering decision (prologue) + direction d = B^-1 A[:,j] + ratio-test partials
+//   primal_solvers.py:110-167, dual: :234 via pivot, bounded: special_solvers.py:239-329
+// One wave per row of B^-1 (coalesced 16-byte loads along the row); the column a_j is read from the
+// transposed copy At (contiguous).  8 m^2 B of HBM traffic.
+// ---------------------------------------------------------------------------------------------------------
+enum { DIR_PRIMAL = 0, DIR_DUAL = 1, DIR_BOUNDED = 2, DIR_FORCED = 3 };
+#define DIR_ROWS_PER_WAVE 4
+#define DIR_ROWS_PER_BLOCK (DIR_ROWS_PER_WAVE * LPX_WAVES)
+
+struct DirArgs {
+    lpx_revised s;
+    int kind;
+    int64_t forced_j;
+    int64_t nprice; // number of pricing partials
+    Partials price, ratio;
+    double *d;
+};
+
+template <typename AccT>
+__device__ __forceinline__ double dir_row(const double *Bi, const float *aj, int64_t m)
+{
+    const int lane = threadIdx.x & 63;
+    AccT acc0 = (AccT)0, acc1 = (AccT)0;
+    const int64_t m2 = m & ~(int64_t)1;
+    for (int64_t k = lane * 2; k < m2; k += 128) {
+        const d2_t bv = *(const d2_t *)(Bi + k);
+        const f2_t av = *(const f2_t *)(aj + k);
+        acc0 = fma((AccT)bv.x, (AccT)av.x, acc0);
+        acc1 = fma((AccT)bv.y, (AccT)av.y, acc1);
+    }
+    if ((m & 1) && lane == 0) acc0 = fma((AccT)Bi[m - 1], (AccT)aj[m - 1], acc0);
+    return (double)wave_sum<AccT>(acc0 + acc1);
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_direction(DirArgs a)
+{
+    __shared__ BlockRed red;
+    __shared__ double sv0[LPX_WAVES], sv1[LPX_WAVES], sv2[LPX_WAVES];
+    __shared__ int64_t si0[LPX_WAVES], si1[LPX_WAVES];
+    lpx_ctrl *ctrl = a.s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const bool f32 = ctrl->f32_phase != 0;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    int64_t j = a.forced_j;
+    double sign = 1.0;
+
+    if (a.kind == DIR_PRIMAL) {
+        const double mn = combine_min(a.price.v0, a.nprice, red);
+        j = combine_imin(a.price.i0, a.nprice, red);
+        const bool opt = lpx_is_optimal_min(mn);
+        if (lead) {
+            ctrl->counter += 1;
+            ctrl->price_val = mn;
+            if (opt) ctrl->status = LPX_OPTIMAL;
+            else ctrl->enter_j = j;
+        }
+        if (opt) return;
+    } else if (a.kind == DIR_BOUNDED) {
+        // first argmax over the partials: value descending, index ascending
+        VI b{LPX_INF, LPX_NOIDX};
+        for (int64_t k = threadIdx.x; k < a.nprice; k += LPX_BLOCK)
+            if (vi_less(-a.price.v0[k], a.price.i0[k], b.v, b.i)) { b.v = -a.price.v0[k]; b.i = a.price.i0[k]; }
+        b = block_argmin(b, red);
+        const double mx = -b.v;
+        j = b.i;
+        const bool opt = lpx_is_optimal_max(mx);
+        int32_t vs = LPX_VS_BASIC;
+        if (!opt) vs = a.s.var_state[j];
+        const bool bad = !opt && vs != LPX_VS_LOWER && vs != LPX_VS_UPPER;
+        if (lead) {
+            ctrl->counter += 1;
+            ctrl->price_val = mx;
+            if (opt) ctrl->status = LPX_OPTIMAL;
+            else if (bad) ctrl->status = LPX_NOT_NONBASIC;
+            else ctrl->enter_j = j;
+        }
+        if (opt || bad) return;
+        sign = (vs == LPX_VS_LOWER) ? 1.0 : -1.0;
+    } else if (a.kind == DIR_DUAL) {
+        const VI t = combine_argmin(a.price.v0, a.price.i0, a.nprice, red);
+        const double rmin = combine_min(a.price.v1, a.nprice, red);
+        j = t.i;
+        const bool unb = rmin >= 0.0; // dual_solvers.py:56-59
+        if (lead) {
+            ctrl->ratio_val = t.v;
+            ctrl->aux_val = rmin;
+            if (unb) ctrl->status = LPX_DUAL_UNBOUNDED;
+            else ctrl->enter_j = j;
+        }
+        if (unb) return;
+    } else {
+        if (lead) ctrl->enter_j = j;
+    }
+
+    const int64_t m = a.s.m;
+    const float *aj = a.s.At + j * a.s.ldAt;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t rbase = (int64_t)blockIdx.x * DIR_ROWS_PER_BLOCK + wave * DIR_ROWS_PER_WAVE;
+    VI t1{LPX_INF, LPX_NOIDX}, t2{LPX_INF, LPX_NOIDX};
+    double dmax = -LPX_INF;
+    for (int q = 0; q < DIR_ROWS_PER_WAVE; ++q) {
+        const int64_t i = rbase + q;
+        if (i >= m) break; // wave-uniform
+        const double *Bi = a.s.Binv + i * a.s.ldB;
+        const double di = f32 ? dir_row<float>(Bi, aj, m) : dir_row<double>(Bi, aj, m);
+        if (lane == 0) a.d[i] = di;
+        if (a.kind == DIR_PRIMAL) {
+            const double th = lpx_psd(a.s.xB[i], di, f32);
+            if (vi_less(th, i, t1.v, t1.i)) { t1.v = th; t1.i = i; }
+            dmax = fmax(dmax, di);
+        } else if (a.kind == DIR_BOUNDED) {
+            const int64_t bi = a.s.basis[i];
+            const double x = a.s.xB[i];
+            const double g1 = lpx_psd(x - a.s.lb[bi], sign * di, false);
+            const double g2 = lpx_psd(a.s.ub[bi] - x, -sign * di, false);
+            if (vi_less(g1, i, t1.v, t1.i)) { t1.v = g1; t1.i = i; }
+            if (vi_less(g2, i, t2.v, t2.i)) { t2.v = g2; t2.i = i; }
+        }
+    }
+    if (a.kind == DIR_PRIMAL || a.kind == DIR_BOUNDED) {
+        // every lane of a wave holds the same values: combine the 4 waves through LDS
+        if (lane == 0) {
+            sv0[wave] = t1.v; si0[wave] = t1.i;
+            sv1[wave] = t2.v; si1[wave] = t2.i;
+            sv2[wave] = dmax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < LPX_WAVES; ++w) {
+                if (vi_less(sv0[w], si0[w], sv0[0], si0[0])) { sv0[0] = sv0[w]; si0[0] = si0[w]; }
+                if (vi_less(sv1[w], si1[w], sv1[0], si1[0])) { sv1[0] = sv1[w]; si1[0] = si1[w]; }
+                sv2[0] = fmax(sv2[0], sv2[w]);
+            }
+            a.ratio.v0[blockIdx.x] = sv0[0];
+            a.ratio.i0[blockIdx.x] = si0[0];
+            if (a.kind == DIR_PRIMAL) {
+                a.ratio.v1[blockIdx.x] = sv2[0];
+            } else {
+                a.ratio.v1[blockIdx.x] = sv1[0];
+                a.ratio.i1[blockIdx.x] = si1[0];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1 prologue ("prepare"): leaving decision, eta column, copy of the old pivot row, bookkeeping
+//   primal_solvers.py:130-132, :165-166, :235-244, :261 ; bounded: special_solvers.py:252-339
+// ---------------------------------------------------------------------------------------------------------
+enum { PREP_PRIMAL = 0, PREP_DUAL = 1, PREP_BOUNDED = 2, PREP_FORCED = 3 };
+struct PrepArgs {
+    lpx_revised s;
+    int kind;
+    int64_t forced_r;
+    int64_t nratio;
+    Partials ratio;
+    const double *d;
+    double *e, *rowr, *scal;
+};
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_prepare(PrepArgs a)
+{
+    __shared__ BlockRed red;
+    lpx_ctrl *ctrl = a.s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    const int64_t m = a.s.m;
+    const int64_t j = ctrl->enter_j;
+    int64_t r = a.forced_r;
+    double theta = 0.0;
+    int32_t leave_state = LPX_VS_LOWER;
+    if (a.kind == PREP_PRIMAL) {
+        const VI t = combine_argmin(a.ratio.v0, a.ratio.i0, a.nratio, red);
+        const double dmax = combine_max(a.ratio.v1, a.nratio, red);
+        r = t.i;
+        theta = t.v;
+        if (dmax <= 0.0) { // primal_solvers.py:144-147
+            if (lead) {
+                ctrl->aux_val = dmax;
+                ctrl->status = LPX_PRIMAL_UNBOUNDED;
+            }
+            return;
+        }
+        if (lead) ctrl->aux_val = dmax;
+    } else if (a.kind == PREP_DUAL) {
+        r = ctrl->leave_r;
+    } else if (a.kind == PREP_BOUNDED) {
+        const VI t1 = combine_argmin(a.ratio.v0, a.ratio.i0, a.nratio, red);
+        const VI t2 = combine_argmin(a.ratio.v1, a.ratio.i1, a.nratio, red);
+        const double g3 = a.s.ub[j] - a.s.lb[j];
+        const double delta = fmin(t1.v, t2.v);
+        if (delta == LPX_INF) { // special_solvers.py:256-257 / :302-303
+            if (lead) ctrl->status = LPX_PRIMAL_UNBOUNDED;
+            return;
+        }
+        if (g3 <= delta) { // bound flip, special_solvers.py:264-268 / :309-313
+            if (lead) {
+                const int32_t vs = a.s.var_state[j];
+                a.s.var_state[j] = (vs == LPX_VS_LOWER) ? LPX_VS_UPPER : LPX_VS_LOWER;
+                if (a.s.log && ctrl->pivots < a.s.log_cap) {
+                    a.s.log[3 * ctrl->pivots + 0] = -1;
+                    a.s.log[3 * ctrl->pivots + 1] = j;
+                    a.s.log[3 * ctrl->pivots + 2] = -1;
+                }
+                ctrl->pivots += 1;
+                ctrl->flip = 1;
+                ctrl->leave_r = -1;
+                ctrl->leave_var = -1;
+                ctrl->ratio_val = g3;
+            }
+            return;
+        }
+        if (t1.v < t2.v) { r = t1.i; leave_state = LPX_VS_LOWER; theta = t1.v; } // :271-277
+        else { r = t2.i; leave_state = LPX_VS_UPPER; theta = t2.v; }              // :278-284
+    }
+
+    const double dr = a.d[r];
+    const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (gi < m) a.e[gi] = (gi == r) ? 1.0 / dr : (-a.d[gi]) / dr; // primal_solvers.py:236-244
+    if (gi < lpx_roundup_dev(m, 2)) a.rowr[gi] = a.s.Binv[r * a.s.ldB + gi]; // K1 reads 2-wide: even length <= ldB
+    if (lead) {
+        const int64_t leaving = a.s.basis[r];
+        a.scal[0] = a.s.xB[r];
+        a.s.basis[r] = j; // primal_solvers.py:261
+        a.s.var_state[leaving] = leave_state;
+        a.s.var_state[j] = LPX_VS_BASIC;
+        if (a.s.log && ctrl->pivots < a.s.log_cap) {
+            a.s.log[3 * ctrl->pivots + 0] = r;
+            a.s.log[3 * ctrl->pivots + 1] = j;
+            a.s.log[3 * ctrl->pivots + 2] = leaving;
+        }
+        ctrl->pivots += 1;
+        ctrl->leave_r = r;
+        ctrl->leave_var = leaving;
+        ctrl->leave_state = leave_state;
+        ctrl->ratio_val = theta;
+        ctrl->flip = 0;
+        ctrl->f32_phase = 0; // E is float64 (np.eye): everything is float64 from here on
+    }
+}
+
+// bounded: clear the flip flag at the start of an iteration (single thread; the previous iteration's update
+// kernel has consumed it)
+__global__ void k_clear_flip(lpx_ctrl *ctrl)
+{
+    if (ctrl->status == LPX_RUNNING) ctrl->flip = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bounded x_B recomputation  special_solvers.py:169-175:  w = b - A_lb lb - A_ub ub ; x_B = B^-1 w
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPX_BLOCK) void k_bounded_w(lpx_revised s, double *w)
+{
+    if (s.ctrl->status != LPX_RUNNING && s.ctrl->status != LPX_OPTIMAL) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * LPX_WAVES + wave;
+    if (i >= s.m) return;
+    const float *Ai = s.A + i * s.ldA;
+    double accl = 0.0, accu = 0.0;
+    for (int64_t j = lane; j < s.n; j += 64) {
+        const int32_t vs = s.var_state[j];
+        if (vs == LPX_VS_LOWER) accl = fma((double)Ai[j], s.lb[j], accl);
+        else if (vs == LPX_VS_UPPER) accu = fma((double)Ai[j], s.ub[j], accu);
+    }
+    accl = wave_sum<double>(accl);
+    accu = wave_sum<double>(accu);
+    if (lane == 0) w[i] = ((double)s.b[i] - accl) - accu;
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_rowdot(const double *M, int64_t ld, int64_t rows, int64_t cols,
+                                                      const double *v, double *out, const lpx_ctrl *ctrl)
+{
+    if (ctrl->status != LPX_RUNNING && ctrl->status != LPX_OPTIMAL) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * LPX_WAVES + wave;
+    if (i >= rows) return;
+    const double *Mi = M + i * ld;
+    double acc = 0.0;
+    for (int64_t k = lane; k < cols; k += 64) acc = fma(Mi[k], v[k], acc);
+    acc = wave_sum<double>(acc);
+    if (lane == 0) out[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// result expansion  primal_solvers.py:72-79 / special_solvers.py:201-206
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPX_BLOCK) void k_expand_fill(lpx_revised s, double *x)
+{
+    const int64_t j = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (j >= s.n) return;
+    double v = 0.0;
+    if (s.lb != nullptr) {
+        const int32_t vs = s.var_state[j];
+        if (vs == LPX_VS_LOWER) v = s.lb[j];
+        else if (vs == LPX_VS_UPPER) v = s.ub[j];
+    }
+    x[j] = v;
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_expand_scatter(const double *xB, const int64_t *basis, int64_t m,
+                                                              double *x)
+{
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i < m) x[basis[i]] = xB[i];
+}
+// cost = dot(c, x): one workgroup, fixed summation tree (deterministic)
+__global__ __launch_bounds__(1024) void k_cost(const float *c, const double *x, int64_t n, double *cost)
+{
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 1024) acc = fma((double)c[j], x[j], acc);
+    acc = wave_sum<double>(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *cost = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side drivers
+// ---------------------------------------------------------------------------------------------------------
+static int check_revised(const lpx_revised *s)
+{
+    LPX_REQUIRE(s != nullptr, "null state");
+    LPX_REQUIRE(s->m > 0 && s->n > 0, "empty problem");
+    LPX_REQUIRE(s->ldA >= s->n && (s->ldA % 4) == 0, "ldA must be >= n and a multiple of 4");
+    LPX_REQUIRE(s->ldAt >= s->m && (s->ldAt % 4) == 0, "ldAt must be >= m and a multiple of 4");
+    LPX_REQUIRE(s->ldB >= s->m && (s->ldB % 2) == 0, "ldB must be >= m and a multiple of 2");
+    LPX_REQUIRE(s->A && s->At && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl,
+                "null device pointer");
+    LPX_REQUIRE(lpx_aligned16(s->A) && lpx_aligned16(s->At) && lpx_aligned16(s->Binv) && lpx_aligned16(s->workspace),
+                "A, At, Binv and workspace must be 16-byte aligned");
+    LPX_REQUIRE(s->workspace != nullptr && s->workspace_bytes >= lpx_revised_workspace_bytes(s->m, s->n),
+                "workspace too small (see lpx_revised_workspace_bytes)");
+    LPX_REQUIRE(lpx_cdiv(s->n, LPX_BLOCK) <= LPX_MAXP && lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK) <= LPX_MAXP,
+                "problem too large for the partial arrays (n <= 524288, m <= 32768)");
+    return LPX_OK;
+}
+
+static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
+{
+    ColsumArgs a{};
+    a.M = s->Binv; a.ld = s->ldB; a.rows = s->m; a.cols = s->m; a.rpc = w.py.rpc;
+    a.wmode = W_CB; a.c = s->c; a.basis = s->basis;
+    a.part = w.ypart; a.ldp = w.ldyp; a.ctrl = s->ctrl;
+    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
+{
+    ColsumArgs a{};
+    a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = s->n; a.rpc = w.pa.rpc;
+    a.wmode = wmode; a.wvec = w.y; a.Binv = s->Binv; a.ldB = s->ldB;
+    a.part = part; a.ldp = w.ldzp; a.ctrl = s->ctrl;
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, double *rc_out, hipStream_t st)
+{
+    FinArgs a{};
+    a.mode = mode; a.ctrl = s->ctrl; a.c = s->c; a.var_state = s->var_state; a.P = w.price;
+    if (mode == FIN_Y) {
+        a.cols = s->m; a.nch = w.py.nch; a.ldp = w.ldyp; a.part = w.ypart; a.out = w.y;
+    } else {
+        a.cols = s->n; a.nch = w.pa.nch; a.ldp = w.ldzp; a.part = w.zpart; a.part2 = w.zpart2;
+        a.out = rc_out ? rc_out : w.rc; a.out2 = w.row;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(a.cols, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+}
+// y = c_B B^-1, z = y A  (3 launches)
+static void launch_pricing_sums(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
+{
+    launch_colsum_B(s, w, st);
+    launch_fin(s, w, FIN_Y, nullptr, st);
+    launch_colsum_A(s, w, W_VEC, w.zpart, st);
+}
+static void launch_direction(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_j, hipStream_t st)
+{
+    DirArgs a{};
+    a.s = *s; a.kind = kind; a.forced_j = forced_j; a.nprice = lpx_cdiv(s->n, LPX_BLOCK);
+    a.price = w.price; a.ratio = w.ratio; a.d = w.d;
+    hipLaunchKernelGGL(k_direction, dim3((unsigned)lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_prepare(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_r, hipStream_t st)
+{
+    PrepArgs a{};
+    a.s = *s; a.kind = kind; a.forced_r = forced_r; a.nratio = lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK);
+    a.ratio = w.ratio; a.d = w.d; a.e = w.e; a.rowr = w.rowr; a.scal = w.scal;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)lpx_cdiv(lpx_roundup(s->m, 2), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_update(const lpx_revised *s, const RevisedWs &w, bool update_xB, hipStream_t st)
+{
+    Rank1Args a{};
+    a.M = s->Binv; a.rows = s->m; a.cols = s->m; a.ld = s->ldB; a.e = w.e; a.rowr = w.rowr; a.r = -1;
+    a.ctrl = s->ctrl; a.xB = update_xB ? s->xB : nullptr; a.xr_old = w.scal; a.col0 = 0;
+    const Rank1Plan p = lpx_rank1_plan(s->m, s->m);
+    a.rows_per_block = p.rows_per_block;
+    hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_bounded_bfs(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bounded_w, dim3((unsigned)lpx_cdiv(s->m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st, *s, w.w);
+    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)lpx_cdiv(s->m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st,
+                       (const double *)s->Binv, s->ldB, s->m, s->m, (const double *)w.w, s->xB,
+                       (const lpx_ctrl *)s->ctrl);
+}
+
+extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "bad kind");
+    LPX_REQUIRE(kind != LPX_KIND_BOUNDED || (s->lb && s->ub), "bounded solver needs lb/ub");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t it = 0; it < iters; ++it) {
+        if (kind == LPX_KIND_PRIMAL) {
+            launch_pricing_sums(s, w, st);
+            launch_fin(s, w, FIN_PRIMAL, nullptr, st);
+            launch_direction(s, w, DIR_PRIMAL, -1, st);
+            launch_prepare(s, w, PREP_PRIMAL, -1, st);
+            launch_update(s, w, true, st);
+        } else if (kind == LPX_KIND_DUAL) {
+            hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)s->xB, s->m, s->ctrl);
+            launch_colsum_A(s, w, W_BINV_ROW, w.zpart2, st);
+            launch_pricing_sums(s, w, st);
+            launch_fin(s, w, FIN_DUAL, nullptr, st);
+            launch_direction(s, w, DIR_DUAL, -1, st);
+            launch_prepare(s, w, PREP_DUAL, -1, st);
+            launch_update(s, w, true, st);
+        } else {
+            hipLaunchKernelGGL(k_clear_flip, dim3(1), dim3(1), 0, st, s->ctrl);
+            launch_pricing_sums(s, w, st);
+            launch_fin(s, w, FIN_BOUNDED, nullptr, st);
+            launch_direction(s, w, DIR_BOUNDED, -1, st);
+            launch_prepare(s, w, PREP_BOUNDED, -1, st);
+            launch_update(s, w, false, st);
+            launch_bounded_bfs(s, w, st);
+        }
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(row >= 0 && row < s->m && col >= 0 && col < s->n, "pivot position out of range");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    launch_direction(s, w, DIR_FORCED, col, st);
+    launch_prepare(s, w, PREP_FORCED, row, st);
+    launch_update(s, w, true, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_bounded_update_bfs(const lpx_revised *s, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(s->lb && s->ub, "bounded solver needs lb/ub");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    launch_bounded_bfs(s, w, (hipStream_t)stream);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_revised_reduced_costs(const lpx_revised *s, int bounded, double *rc_out, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(rc_out != nullptr, "null output");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    launch_pricing_sums(s, w, st);
+    launch_fin(s, w, bounded ? FIN_BOUNDED : FIN_PRIMAL, rc_out, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_revised_expand(const lpx_revised *s, double *x, double *cost, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(x != nullptr && cost != nullptr, "null output");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_expand_fill, dim3((unsigned)lpx_cdiv(s->n, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, x);
+    hipLaunchKernelGGL(k_expand_scatter, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st,
+                       (const double *)s->xB, (const int64_t *)s->basis, s->m, x);
+    hipLaunchKernelGGL(k_cost, dim3(1), dim3(1024), 0, st, s->c, (const double *)x, s->n, cost);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// primal-dual restricted-problem updates  special_solvers.py:405-444
+// The restricted primal is the full matrix [A | I] (n = n_orig + m columns) with inadmissible columns
+// EXCLUDED; the artificial block stays in.  v = y A and u = y_rp A reuse the column-sum kernels.
+// ---------------------------------------------------------------------------------------------------------
+struct PdArgs {
+    int64_t n_orig, nch, ldp, m;
+    const double *part;
+    const double *c64;
+    double *v;
+    int32_t *var_state;
+    const double *vprev;
+    const double *yrp;
+    Partials P;
+};
+__global__ __launch_bounds__(LPX_BLOCK) void k_pd_admissible(PdArgs a)
+{
+    const int64_t col = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (col >= a.n_orig) return;
+    const double v = fin_sum<double>(a.part, a.nch, a.ldp, col);
+    a.v[col] = v;
+    const double c = a.c64[col];
+    const bool adm = fabs(v - c) <= LPX_ATOL + LPX_RTOL * fabs(c); // np.isclose(y @ A, c)
+    a.var_state[col] = adm ? LPX_VS_LOWER : LPX_VS_EXCLUDED;
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_pd_theta(PdArgs a)
+{
+    __shared__ BlockRed red;
+    const int64_t col = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    double th = LPX_INF, um = -LPX_INF;
+    if (col < a.n_orig) {
+        const double u = fin_sum<double>(a.part, a.nch, a.ldp, col);
+        const int32_t vs = a.var_state[col];
+        if (vs == LPX_VS_EXCLUDED) th = lpx_psd(a.c64[col] - a.vprev[col], u, false);
+        else um = u;
+    }
+    if (col < a.m) um = fmax(um, a.yrp[col]); // artificial block of A_rp: y_rp @ I
+    th = block_min(th, red);
+    um = block_max(um, red);
+    if (threadIdx.x == 0) {
+        a.P.v0[blockIdx.x] = th;
+        a.P.v1[blockIdx.x] = um;
+    }
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_pd_axpy(Partials P, int64_t np, const double *yrp, double *y, int64_t m,
+                                                      double *out)
+{
+    __shared__ BlockRed red;
+    const double th = combine_min(P.v0, np, red);
+    const double um = combine_max(P.v1, np, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = th;
+        out[1] = um;
+    }
+    if (um <= 0.0) return; // DualIsUnboundedError, special_solvers.py:435-436
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i < m) y[i] = y[i] + th * yrp[i]; // :444  (numpy: theta * y_rp, then +=; two roundings)
+}
+// forces status RUNNING-independent execution of the column-sum kernels: they gate on ctrl->status, which is
+// OPTIMAL after the inner solve, so the primal-dual steps run them with a scratch control block.
+__global__ void k_ctrl_scratch(lpx_ctrl *c)
+{
+    c->status = LPX_RUNNING;
+    c->f32_phase = 0;
+    c->leave_r = 0;
+}
+
+extern "C" int lpx_pd_admissible(const lpx_revised *s, const double *y, const double *c64, int64_t n_orig, double *v,
+                                 void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(y && c64 && v && n_orig > 0 && n_orig <= s->n, "bad arguments");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    lpx_ctrl *scr = w.scr_ctrl;
+    hipLaunchKernelGGL(k_ctrl_scratch, dim3(1), dim3(1), 0, st, scr);
+    ColsumArgs a{};
+    a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = n_orig; a.rpc = w.pa.rpc;
+    a.wmode = W_VEC; a.wvec = y; a.part = w.zpart; a.ldp = w.ldzp; a.ctrl = scr;
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+    PdArgs p{};
+    p.n_orig = n_orig; p.nch = w.pa.nch; p.ldp = w.ldzp; p.m = s->m; p.part = w.zpart; p.c64 = c64; p.v = v;
+    p.var_state = s->var_state;
+    hipLaunchKernelGGL(k_pd_admissible, dim3((unsigned)lpx_cdiv(n_orig, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, p);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c64, const double *v, int64_t n_orig,
+                                double *out, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(y && c64 && v && out && n_orig > 0 && n_orig <= s->n, "bad arguments");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    lpx_ctrl *scr = w.scr_ctrl;
+    hipLaunchKernelGGL(k_ctrl_scratch, dim3(1), dim3(1), 0, st, scr);
+    // y_rp = c_B B^-1 of the solved restricted primal (float64 inverse; the reference re-inverts in float32)
+    ColsumArgs b{};
+    b.M = s->Binv; b.ld = s->ldB; b.rows = s->m; b.cols = s->m; b.rpc = w.py.rpc;
+    b.wmode = W_CB; b.c = s->c; b.basis = s->basis; b.part = w.ypart; b.ldp = w.ldyp; b.ctrl = scr;
+    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(LPX_BLOCK), 0, st, b);
+    FinArgs f{};
+    f.mode = FIN_Y; f.ctrl = scr; f.cols = s->m; f.nch = w.py.nch; f.ldp = w.ldyp; f.part = w.ypart; f.out = w.y;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, f);
+    ColsumArgs a{};
+    a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = n_orig; a.rpc = w.pa.rpc;
+    a.wmode = W_VEC; a.wvec = w.y; a.part = w.zpart; a.ldp = w.ldzp; a.ctrl = scr;
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+    PdArgs p{};
+    p.n_orig = n_orig; p.nch = w.pa.nch; p.ldp = w.ldzp; p.m = s->m; p.part = w.zpart; p.c64 = c64;
+    p.var_state = s->var_state; p.vprev = v; p.yrp = w.y; p.P = w.price;
+    const int64_t nb = lpx_cdiv(n_orig > s->m ? n_orig : s->m, LPX_BLOCK);
+    hipLaunchKernelGGL(k_pd_theta, dim3((unsigned)nb), dim3(LPX_BLOCK), 0, st, p);
+    hipLaunchKernelGGL(k_pd_axpy, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, w.price, nb,
+                       (const double *)w.y, y, s->m, out);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// individually exported kernels (unit tests against the oracle; bench of K1)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPX_BLOCK) void k_copy_row(const double *src, double *dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+static int g_rank1_nt = -1;
+static bool rank1_use_nt()
+{
+    if (g_rank1_nt < 0) {
+        const char *e = getenv("LPX_RANK1_NT");
+        g_rank1_nt = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_rank1_nt == 1;
+}
+
+extern "C" int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
+                                double *rowr_scratch, void *stream)
+{
+    LPX_REQUIRE(M && e && rowr_scratch, "null pointer");
+    LPX_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld % 2) == 0, "ld must be >= cols and even");
+    LPX_REQUIRE(r >= 0 && r < rows, "pivot row out of range");
+    LPX_REQUIRE(lpx_aligned16(M) && lpx_aligned16(rowr_scratch), "M and rowr_scratch must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_copy_row, dim3((unsigned)lpx_cdiv(ld, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st,
+                       (const double *)(M + r * ld), rowr_scratch, ld);
+    Rank1Args a{};
+    a.M = M; a.rows = rows; a.cols = cols; a.ld = ld; a.e = e; a.rowr = rowr_scratch; a.r = r; a.ctrl = nullptr;
+    const Rank1Plan p = lpx_rank1_plan(rows, cols);
+    a.rows_per_block = p.rows_per_block;
+    if (rank1_use_nt()) hipLaunchKernelGGL((k_rank1<false, true>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_eta(const double *d, int64_t m, int64_t r, double *e)
+{
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const double dr = d[r];
+    e[i] = (i == r) ? 1.0 / dr : (-d[i]) / dr;
+}
+extern "C" int lpx_eta(const double *d, int64_t m, int64_t r, double *e, void *stream)
+{
+    LPX_REQUIRE(d && e && m > 0 && r >= 0 && r < m, "bad arguments");
+    hipLaunchKernelGGL(k_eta, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, (hipStream_t)stream, d, m, r, e);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// Generic two-stage reductions over a vector: stage 1 = per-workgroup partials, stage 2 = one workgroup.
+enum { RED_FIRST_NEG = 0, RED_ARGMAX = 1, RED_RATIO_PRIMAL = 2, RED_RATIO_DUAL = 3, RED_RATIO_BOUNDED = 4 };
+struct RedArgs {
+    int op;
+    int64_t n;
+    const double *a, *b, *c, *d;
+    const int32_t *var_state;
+    int f32;
+    double sign;
+    Partials P;
+    double *out_val;
+    int64_t *out_idx;
+};
+__global__ __launch_bounds__(LPX_BLOCK) void k_red_stage1(RedArgs a)
+{
+    __shared__ BlockRed red;
+    const int64_t k = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const bool in = k < a.n && !(a.var_state && a.var_state[k] == LPX_VS_EXCLUDED);
+    const bool f32 = a.f32 != 0;
+    if (a.op == RED_FIRST_NEG) {
+        const double v = in ? a.a[k] : LPX_INF;
+        const double mn = block_min(v, red);
+        const int64_t j = block_imin((in && v < 0.0) ? k : LPX_NOIDX, red);
+        if (threadIdx.x == 0) { a.P.v0[blockIdx.x] = mn; a.P.i0[blockIdx.x] = j; }
+    } else if (a.op == RED_ARGMAX) {
+        VI t{in ? -a.a[k] : LPX_INF, in ? k : LPX_NOIDX};
+        t = block_argmin(t, red);
+        if (threadIdx.x == 0) { a.P.v0[blockIdx.x] = -t.v; a.P.i0[blockIdx.x] = t.i; }
+    } else if (a.op == RED_RATIO_PRIMAL) {
+        VI t{in ? lpx_psd(a.a[k], a.b[k], f32) : LPX_INF, in ? k : LPX_NOIDX};
+        t = block_argmin(t, red);
+        const double dm = block_max(in ? a.b[k] : -LPX_INF, red);
+        if (threadIdx.x == 0) { a.P.v0[blockIdx.x] = t.v; a.P.i0[blockIdx.x] = t.i; a.P.v1[blockIdx.x] = dm; }
+    } else if (a.op == RED_RATIO_DUAL) {
+        VI t{in ? lpx_dsd(a.a[k], a.b[k], f32) : LPX_INF, in ? k : LPX_NOIDX};
+        t = block_argmin(t, red);
+        const double rm = block_min(in ? a.b[k] : LPX_INF, red);
+        if (threadIdx.x == 0) { a.P.v0[blockIdx.x] = t.v; a.P.i0[blockIdx.x] = t.i; a.P.v1[blockIdx.x] = rm; }
+    } else {
+        VI t1{LPX_INF, LPX_NOIDX}, t2{LPX_INF, LPX_NOIDX};
+        if (in) {
+            t1.v = lpx_psd(a.a[k] - a.c[k], a.sign * a.b[k], false);
+            t2.v = lpx_psd(a.d[k] - a.a[k], -a.sign * a.b[k], false);
+            t1.i = t2.i = k;
+        }
+        t1 = block_argmin(t1, red);
+        t2 = block_argmin(t2, red);
+        if (threadIdx.x == 0) {
+            a.P.v0[blockIdx.x] = t1.v; a.P.i0[blockIdx.x] = t1.i;
+            a.P.v1[blockIdx.x] = t2.v; a.P.i1[blockIdx.x] = t2.i;
+        }
+    }
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_red_stage2(RedArgs a, int64_t np)
+{
+    __shared__ BlockRed red;
+    if (a.op == RED_FIRST_NEG) {
+        const double mn = combine_min(a.P.v0, np, red);
+        const int64_t j = combine_imin(a.P.i0, np, red);
+        if (threadIdx.x == 0) { a.out_val[0] = mn; a.out_idx[0] = (j == LPX_NOIDX) ? -1 : j; }
+    } else if (a.op == RED_ARGMAX) {
+        VI b{LPX_INF, LPX_NOIDX};
+        for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK)
+            if (vi_less(-a.P.v0[k], a.P.i0[k], b.v, b.i)) { b.v = -a.P.v0[k]; b.i = a.P.i0[k]; }
+        b = block_argmin(b, red);
+        if (threadIdx.x == 0) { a.out_val[0] = -b.v; a.out_idx[0] = b.i; }
+    } else if (a.op == RED_RATIO_PRIMAL) {
+        const VI t = combine_argmin(a.P.v0, a.P.i0, np, red);
+        const double dm = combine_max(a.P.v1, np, red);
+        if (threadIdx.x == 0) { a.out_val[0] = t.v; a.out_val[1] = dm; a.out_idx[0] = t.i; }
+    } else if (a.op == RED_RATIO_DUAL) {
+        const VI t = combine_argmin(a.P.v0, a.P.i0, np, red);
+        const double rm = combine_min(a.P.v1, np, red);
+        if (threadIdx.x == 0) { a.out_val[0] = t.v; a.out_val[1] = rm; a.out_idx[0] = t.i; }
+    } else {
+        const VI t1 = combine_argmin(a.P.v0, a.P.i0, np, red);
+        const VI t2 = combine_argmin(a.P.v1, a.P.i1, np, red);
+        if (threadIdx.x == 0) { a.out_val[0] = t1.v; a.out_val[1] = t2.v; a.out_idx[0] = t1.i; a.out_idx[1] = t2.i; }
+    }
+}
+extern "C" int64_t lpx_reduce_scratch_bytes(void) { return 4 * lpx_roundup(8 * LPX_MAXP, 256); }
+static int run_reduction(RedArgs a, void *scratch, void *stream)
+{
+    LPX_REQUIRE(scratch && a.out_val && a.out_idx && a.n > 0, "bad arguments");
+    const int64_t np = lpx_cdiv(a.n, LPX_BLOCK);
+    LPX_REQUIRE(np <= LPX_MAXP, "vector too long for the partial arrays");
+    char *p = (char *)scratch;
+    carve_partials(p, a.P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_red_stage1, dim3((unsigned)np), dim3(LPX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_red_stage2, dim3(1), dim3(LPX_BLOCK), 0, st, a, np);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_price_first_negative(const double *rc, const int32_t *var_state, int64_t n, double *out_val,
+                                        int64_t *out_idx, void *scratch, void *stream)
+{
+    RedArgs a{};
+    a.op = RED_FIRST_NEG; a.n = n; a.a = rc; a.var_state = var_state; a.out_val = out_val; a.out_idx = out_idx;
+    LPX_REQUIRE(rc != nullptr, "null input");
+    return run_reduction(a, scratch, stream);
+}
+extern "C" int lpx_price_argmax(const double *rc, int64_t n, double *out_val, int64_t *out_idx, void *scratch, void *stream)
+{
+    RedArgs a{};
+    a.op = RED_ARGMAX; a.n = n; a.a = rc; a.out_val = out_val; a.out_idx = out_idx;
+    LPX_REQUIRE(rc != nullptr, "null input");
+    return run_reduction(a, scratch, stream);
+}
+extern "C" int lpx_ratio_primal(const double *x, const double *d, int64_t m, int f32, double *out_val, int64_t *out_idx,
+                                void *scratch, void *stream)
+{
+    RedArgs a{};
+    a.op = RED_RATIO_PRIMAL; a.n = m; a.a = x; a.b = d; a.f32 = f32; a.out_val = out_val; a.out_idx = out_idx;
+    LPX_REQUIRE(x && d, "null input");
+    return run_reduction(a, scratch, stream);
+}
+extern "C" int lpx_ratio_dual(const double *rc, const double *row, const int32_t *var_state, int64_t n, int f32,
+                              double *out_val, int64_t *out_idx, void *scratch, void *stream)
+{
+    RedArgs a{};
+    a.op = RED_RATIO_DUAL; a.n = n; a.a = rc; a.b = row; a.var_state = var_state; a.f32 = f32;
+    a.out_val = out_val; a.out_idx = out_idx;
+    LPX_REQUIRE(rc && row, "null input");
+    return run_reduction(a, scratch, stream);
+}
+extern "C" int lpx_ratio_bounded(const double *x, const double *d, const double *lbB, const double *ubB, int64_t m,
+                                 double sign, double *out_val, int64_t *out_idx, void *scratch, void *stream)
+{
+    RedArgs a{};
+    a.op = RED_RATIO_BOUNDED; a.n = m; a.a = x; a.b = d; a.c = lbB; a.d = ubB; a.sign = sign;
+    a.out_val = out_val; a.out_idx = out_idx;
+    LPX_REQUIRE(x && d && lbB && ubB, "null input");
+    return run_reduction(a, scratch, stream);
+}
+extern "C" int lpx_dual_row_select(const double *xB, int64_t m, double *out_val, int64_t *out_idx, void *scratch,
+                                   void *stream)
+{
+    return lpx_price_first_negative(xB, nullptr, m, out_val, out_idx, scratch, stream);
+}

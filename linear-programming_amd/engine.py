@@ -1,0 +1,125 @@
+"""Device-resident solver state and the host side of the pivot loop.
+
+``RevisedEngine`` keeps (A, A^T, b, c, B^-1, x_B, basis, var_state, control block, pivot log, scratch) in HBM
+for the life of a solver object, enqueues iterations through liblpx and reads back one 128-byte control block
+per chunk of iterations -- the only host round trip of the loop (north star: "no per-pivot host round-trip
+beyond a scalar status flag").
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import roundup, stream_ptr, to_device, to_device_2d, torch_cuda
+
+
+class RevisedEngine:
+    """State of one LP in revised form (explicit B^-1, primal_solvers.py:13-41) on the GPU."""
+
+    #: iterations enqueued between two reads of the control block
+    CHUNK = 64
+
+    def __init__(self, c32, A32, b32, basis, inv0, bfs0, var_state=None, lb=None, ub=None, log_cap=0):
+        torch = torch_cuda()
+        self.lib = _lib.load()
+        self.torch = torch
+        m, n = A32.shape
+        self.m, self.n = m, n
+        self.ldA, self.ldAt, self.ldB = roundup(n, 4), roundup(m, 4), roundup(m, 2)
+        self.A = to_device_2d(A32.astype(np.float32, copy=False), self.ldA, torch.float32)
+        self.At = torch.zeros((n, self.ldAt), dtype=torch.float32, device="cuda")
+        self.At[:, :m].copy_(self.A[:, :n].t())
+        self.b = to_device(b32.astype(np.float32, copy=False))
+        self.c = to_device(c32.astype(np.float32, copy=False))
+        self.Binv = to_device_2d(np.asarray(inv0, dtype=np.float64), self.ldB, torch.float64)
+        self.xB = to_device(np.asarray(bfs0, dtype=np.float64))
+        self.basis = to_device(np.asarray(basis, dtype=np.int64))
+        if var_state is None:
+            var_state = np.full(n, _lib.VS_LOWER, dtype=np.int32)
+            var_state[np.asarray(basis, dtype=np.int64)] = _lib.VS_BASIC
+        self.var_state = to_device(np.asarray(var_state, dtype=np.int32))
+        self.lb = None if lb is None else to_device(np.asarray(lb, dtype=np.float64))
+        self.ub = None if ub is None else to_device(np.asarray(ub, dtype=np.float64))
+        self.ctrl = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        self.log_cap = int(log_cap)
+        self.log = torch.zeros((max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
+        ws_bytes = self.lib.lpx_revised_workspace_bytes(m, n)
+        self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+        self.x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        self.cost = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self.host_ctrl = _lib.LpxCtrl()
+
+        s = self.s = _lib.LpxRevised()
+        s.m, s.n, s.ldA, s.ldAt, s.ldB = m, n, self.ldA, self.ldAt, self.ldB
+        s.A, s.At, s.b, s.c = self.A.data_ptr(), self.At.data_ptr(), self.b.data_ptr(), self.c.data_ptr()
+        s.Binv, s.xB, s.basis = self.Binv.data_ptr(), self.xB.data_ptr(), self.basis.data_ptr()
+        s.var_state = self.var_state.data_ptr()
+        s.lb = None if self.lb is None else self.lb.data_ptr()
+        s.ub = None if self.ub is None else self.ub.data_ptr()
+        s.ctrl = self.ctrl.data_ptr()
+        s.log = self.log.data_ptr() if self.log_cap > 0 else None
+        s.log_cap = self.log_cap
+        s.workspace, s.workspace_bytes = self.workspace.data_ptr(), ws_bytes
+        _lib.check(self.lib.lpx_ctrl_init(s.ctrl, 1, stream_ptr()))
+
+    # ------------------------------------------------------------------ control block
+    def read_ctrl(self):
+        _lib.check(self.lib.lpx_read_ctrl(self.s.ctrl, C.byref(self.host_ctrl), stream_ptr()))
+        return self.host_ctrl
+
+    # ------------------------------------------------------------------ loop
+    def run(self, kind, maxiters):
+        """One ``solve(maxiters)`` call of the reference: returns the control block after the loop ended."""
+        st = stream_ptr()
+        _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
+        left = int(maxiters)
+        ctrl = None
+        while left > 0:
+            k = min(left, self.CHUNK)
+            _lib.check(self.lib.lpx_revised_iterate(C.byref(self.s), kind, k, st))
+            left -= k
+            ctrl = self.read_ctrl()
+            if ctrl.status != _lib.RUNNING:
+                break
+        if ctrl is None:
+            ctrl = self.read_ctrl()
+        return ctrl
+
+    def enqueue(self, kind, iters):
+        """Enqueue iterations without reading the control block (bench / timing windows)."""
+        _lib.check(self.lib.lpx_revised_iterate(C.byref(self.s), kind, int(iters), stream_ptr()))
+
+    def pivot(self, row, col):
+        _lib.check(self.lib.lpx_revised_pivot(C.byref(self.s), int(row), int(col), stream_ptr()))
+
+    def bounded_update_bfs(self):
+        _lib.check(self.lib.lpx_bounded_update_bfs(C.byref(self.s), stream_ptr()))
+
+    # ------------------------------------------------------------------ results
+    def expand(self):
+        """(x, cost) on the host: scatter + dot on the device, one D2H copy (primal_solvers.py:72-79)."""
+        _lib.check(self.lib.lpx_revised_expand(C.byref(self.s), self.x.data_ptr(), self.cost.data_ptr(), stream_ptr()))
+        x = self.x.cpu().numpy()
+        return x, np.float64(self.cost.cpu().numpy()[0])
+
+    def reduced_costs(self, bounded=False):
+        rc = self.torch.zeros(self.n, dtype=self.torch.float64, device="cuda")
+        # the kernels gate on status == RUNNING; query on a running control block
+        _lib.check(self.lib.lpx_revised_reduced_costs(C.byref(self.s), int(bounded), rc.data_ptr(), stream_ptr()))
+        return rc.cpu().numpy()
+
+    def host_basis(self):
+        return self.basis.cpu().numpy()
+
+    def host_var_state(self):
+        return self.var_state.cpu().numpy()
+
+    def host_Binv(self):
+        return self.Binv[:, : self.m].cpu().numpy()
+
+    def host_xB(self):
+        return self.xB.cpu().numpy()
+
+    def host_log(self, count):
+        count = min(int(count), self.log_cap)
+        return self.log[:count].cpu().numpy()

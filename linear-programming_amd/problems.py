@@ -18,24 +18,31 @@ def gen_primal(m, n, seed):
     return c, A, b, basis
 
 
-def gen_primal_f32(m, n, seed):
-    """Same LP as gen_primal for large sizes: draws in float32 blocks to bound host memory.
+BLOCK_COLS = 250  # column-block granularity of gen_primal_columns (divides 40000/8, 2000/8, 128/8 is handled by ragged blocks)
 
-    NOT bit-identical to gen_primal (different draw dtype); used only for the 20k x 40k bench workload where
-    a float64 (m, k) draw would need 3.2 GB twice.  Values are float32-representable by construction.
+
+def gen_primal_columns(m, n, seed, j0, j1):
+    """Columns [j0, j1) of the large-scale variant of gen_primal, float32, reproducible under ANY column split.
+
+    A = [G I], G ~ U(0,1) drawn in float32 per block of BLOCK_COLS columns from its own PCG64 stream
+    (SeedSequence([seed, block])), so a rank that owns a column slice generates exactly its part of the one
+    global matrix.  Not bit-identical to gen_primal (different draw order/dtype); same distribution.
+    Returns (A_cols[m, j1-j0] float32, b[m] float32, c[n] float32, basis[m]).
     """
-    rng = np.random.default_rng(seed)
     k = n - m
-    A = np.zeros((m, n), dtype=np.float32)
-    step = 2048
-    for i0 in range(0, m, step):
-        i1 = min(m, i0 + step)
-        A[i0:i1, :k] = rng.random((i1 - i0, k), dtype=np.float32)
-    A[np.arange(m), k + np.arange(m)] = 1.0
+    out = np.zeros((m, j1 - j0), dtype=np.float32)
+    blk0, blk1 = j0 // BLOCK_COLS, (min(j1, k) - 1) // BLOCK_COLS if j0 < k else -1
+    for blk in range(blk0, blk1 + 1):
+        lo, hi = blk * BLOCK_COLS, min((blk + 1) * BLOCK_COLS, k)
+        g = np.random.default_rng([seed, blk]).random((m, hi - lo), dtype=np.float32)
+        a, bnd = max(lo, j0), min(hi, j1)
+        out[:, a - j0:bnd - j0] = g[:, a - lo:bnd - lo]
+    for j in range(max(j0, k), j1):  # identity part
+        out[j - k, j - j0] = 1.0
+    rng = np.random.default_rng([seed, 1 << 30])
     b = (1.0 + rng.random(m, dtype=np.float32)).astype(np.float32)
     c = np.concatenate([-rng.random(k, dtype=np.float32), np.zeros(m, dtype=np.float32)])
-    basis = np.arange(k, n)
-    return c, A, b, basis
+    return out, b, c, np.arange(k, n)
 
 
 def gen_dual(m, n, seed):

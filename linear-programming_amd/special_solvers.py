@@ -1,0 +1,210 @@
+"""Special solvers behind the reference's class API (linprog/special_solvers.py:11-480).
+
+* ``BoundedVariablePrimalSimplexSolver`` -- bounded pricing (float32 reduced costs, largest-coefficient rule),
+  three-way ratio test, bound flips: all on the device (LPX_KIND_BOUNDED).
+* ``PrimalDualAlgorithm`` -- outer loop on the host, every array operation of an outer iteration on the device:
+  admissible mask, restricted primal (= full [A | I] with inadmissible columns excluded, solved by the primal
+  loop from the artificial basis), restricted dual, theta reduction, dual update.
+* ``PhaseOneSimplexSolver`` -- host orchestration around the device primal solver.
+"""
+import numpy as np
+
+from . import _lib
+from .data_classes import LinProgResult
+from .device import stream_ptr, to_device, torch_cuda
+from .engine import RevisedEngine
+from .exceptions import DualIsUnboundedError, PrimalIsInfeasibleError, PrimalIsUnboundedError
+from .preprocessing import ProblemPreprocessingUtils
+from .primal_solvers import PrimalRevisedSimplexSolver, _initial_inverse
+from .utils import get_bounds_on_bfs
+
+
+class PhaseOneSimplexSolver(PrimalRevisedSimplexSolver):
+    """Phase I of the two-phase method (special_solvers.py:11-91): finds a starting basis, sets ``.basis``."""
+
+    def __init__(self, c, A, b):
+        self.c, self.A, self.b = self._preprocess_problem(c, A, b)
+        self.m, self.n = self.A.shape
+        self.row_offset = 1
+        self.col_offset = 1
+        self.basis = None
+
+    def solve(self, maxiters: int = 100):
+        c = np.hstack([np.zeros(self.n), np.ones(self.m)])
+        A = np.hstack([self.A, np.eye(self.m)])
+        b = np.array(self.b)
+        basis = np.arange(self.n, self.n + self.m)
+        solver = PrimalRevisedSimplexSolver(c, A, b, basis)  # the hot path: device primal loop
+        res = solver.solve(maxiters)
+
+        if res.cost > 0:  # special_solvers.py:55-59
+            if res.optimum:
+                raise PrimalIsInfeasibleError
+            raise ValueError("Phase one did not converge.")
+
+        if res.basis.max() >= self.n:
+            # artificial variables still basic at zero level: pivot them out where a positive entry of the
+            # tableau row allows it (special_solvers.py:61-80)
+            for art in range(self.n, self.n + self.m):
+                if art not in res.basis:
+                    continue
+                row = int(np.argmax(res.basis == art))
+                candidates = np.array([j for j in range(self.n) if j not in res.basis])
+                tableau_row = (solver.inv_basis_matrix[row] @ solver.A)[candidates]
+                usable = tableau_row > 0
+                if usable.any():
+                    solver.pivot(row, candidates[np.argmax(usable)])
+                    res = solver._get_solver_return_object()
+
+        if res.basis.max() >= self.n:
+            # remaining artificials mark redundant equations (special_solvers.py:82-89, `<=` kept as is)
+            keep = res.basis <= self.n
+            self.A = self.A[keep]
+            self.b = self.b[keep]
+            self.m = keep.sum()
+            res.basis = res.basis[keep]
+
+        self.basis = res.basis
+
+
+class BoundedVariablePrimalSimplexSolver(PrimalRevisedSimplexSolver):
+    """Primal simplex for lb <= x <= ub without bound rows (special_solvers.py:94-343)."""
+
+    _KIND = _lib.KIND_BOUNDED
+
+    def __init__(self, c, A, b, lb, ub, basis, lb_nonbasic_vars, ub_nonbasic_vars):
+        self.c, self.A, self.b = self._preprocess_problem(c, A, b)
+        self.lb = np.array(lb, dtype=np.float64)
+        self.ub = np.array(ub, dtype=np.float64)
+        self.m, self.n = self.A.shape
+        self.row_offset = 1
+        self.col_offset = 1
+        self.basis = np.array(basis).astype(int)
+        lbn = np.array(lb_nonbasic_vars).astype(int)
+        ubn = np.array(ub_nonbasic_vars).astype(int)
+        # unconstrained variables get the largest magnitude any bfs can reach (special_solvers.py:139-142)
+        M_bounds = get_bounds_on_bfs(self.A, self.b)
+        self.lb[self.lb == -np.inf] = -M_bounds
+        self.ub[self.ub == np.inf] = M_bounds
+        inv32, _ = _initial_inverse(self.A, self.basis, self.b)
+        var_state = np.full(self.n, _lib.VS_EXCLUDED, dtype=np.int32)
+        var_state[lbn] = _lib.VS_LOWER
+        var_state[ubn] = _lib.VS_UPPER
+        var_state[self.basis] = _lib.VS_BASIC
+        self._engine = RevisedEngine(self.c, self.A, self.b, self.basis, inv32, np.zeros(self.m), var_state=var_state,
+                                     lb=self.lb, ub=self.ub, log_cap=self._LOG_CAP)
+        self._engine.bounded_update_bfs()  # special_solvers.py:145
+        self.counter = None
+        self.optimum = None
+
+    @property
+    def lb_nonbasic_vars(self):
+        """Nonbasic variables at their lower bound (ascending; the reference keeps insertion order)."""
+        return np.flatnonzero(self._engine.host_var_state() == _lib.VS_LOWER)
+
+    @property
+    def ub_nonbasic_vars(self):
+        return np.flatnonzero(self._engine.host_var_state() == _lib.VS_UPPER)
+
+    @property
+    def bfs(self):
+        return self._engine.host_xB()  # float64 from the start
+
+    def pivot(self, *args, **kwargs):
+        raise NotImplementedError(
+            "`pivot` operation/method not decoupled from `solve` method for this class."
+        )  # special_solvers.py:216-219
+
+    def _raise_for_status(self, status):
+        if status == _lib.PRIMAL_UNBOUNDED:
+            raise PrimalIsUnboundedError  # special_solvers.py:256-257 / :302-303
+        if status == _lib.NOT_NONBASIC:
+            raise ValueError("Column to enter basis is not nonbasic.")  # :331
+
+
+class PrimalDualAlgorithm:
+    """Primal-dual algorithm (special_solvers.py:346-480).
+
+    The reference derives from DualRevisedSimplexSolver but overrides both ``__init__`` and ``solve`` and
+    uses nothing else of it.
+    """
+
+    def __init__(self, c, A, b):
+        self.c, self.A, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
+        self.m, self.n = self.A.shape
+        self.counter = 0
+        self.optimum = False
+        self.inner_pivot_logs = []  # (row, entering, leaving) in [A | I] numbering, when _LOG_CAP > 0
+        self.admissible_sets = []
+
+    _LOG_CAP = 0
+
+    def solve(self, maxiters1: int = 100, maxiters2: int = 100):
+        torch = torch_cuda()
+        lib = _lib.load()
+        y0 = np.zeros(self.m)
+        expanded = False
+        if self.c.min() < 0:  # special_solvers.py:388-400 (big-M row so that a dual feasible start exists)
+            expanded = True
+            bounding_M = get_bounds_on_bfs(self.A, self.b)
+            self.c = np.hstack([self.c, np.zeros(1)])
+            self.A = np.vstack([np.hstack([self.A, np.zeros((self.m, 1))]), np.ones((1, self.n + 1))])
+            self.b = np.hstack([self.b, self.n * bounding_M * np.ones(1)])
+            self.m, self.n = self.A.shape
+            y0 = np.hstack([y0, self.c.min() * np.ones(1)])
+        m, n = self.m, self.n
+
+        # restricted primal = [A | I] with a per-column admissible mask; costs 0 / 1; artificial starting basis
+        c_rp, A_rp, b_rp = ProblemPreprocessingUtils.preprocess_problem(
+            np.hstack([np.zeros(n), np.ones(m)]), np.hstack([self.A, np.eye(m)]), self.b)
+        art_basis = np.arange(n, n + m)
+        eng = RevisedEngine(c_rp, A_rp, b_rp, art_basis, np.eye(m, dtype=np.float32), b_rp, log_cap=self._LOG_CAP)
+        y = to_device(y0.astype(np.float64))
+        c64 = to_device(np.asarray(self.c, dtype=np.float64))
+        v = torch.zeros(n, dtype=torch.float64, device="cuda")
+        out = torch.zeros(2, dtype=torch.float64, device="cuda")
+        eye = torch.eye(m, dtype=torch.float64, device="cuda")
+        b_dev = to_device(b_rp.astype(np.float64))
+        art_dev = to_device(art_basis.astype(np.int64))
+        st = stream_ptr()
+        import ctypes as C
+
+        x_rp = None
+        inner_basis = art_basis
+        while self.counter < maxiters1:
+            self.counter += 1
+            _lib.check(lib.lpx_pd_admissible(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, v.data_ptr(), st))  # :405
+            # fresh restricted-primal solver state (:408-424): artificial basis, B^-1 = I, bfs = b, float32 phase
+            eng.var_state[n:] = _lib.VS_BASIC
+            eng.Binv.zero_()
+            eng.Binv[:, :m].copy_(eye)
+            eng.xB.copy_(b_dev)
+            eng.basis.copy_(art_dev)
+            _lib.check(lib.lpx_ctrl_init(eng.s.ctrl, 1, st))
+            if self._LOG_CAP:
+                self.admissible_sets.append(np.flatnonzero(eng.host_var_state()[:n] == _lib.VS_LOWER))
+            ctrl = eng.run(_lib.KIND_PRIMAL, maxiters2)  # :425
+            if ctrl.status == _lib.PRIMAL_UNBOUNDED:
+                raise PrimalIsUnboundedError
+            if self._LOG_CAP:
+                self.inner_pivot_logs.append(eng.host_log(ctrl.pivots))
+            x_rp, cost_rp = eng.expand()
+            inner_basis = eng.host_basis()
+            if cost_rp > 0.0:  # :427-444
+                _lib.check(lib.lpx_pd_dual_step(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), v.data_ptr(), n,
+                                                out.data_ptr(), st))
+                theta, umax = out.cpu().numpy()
+                if umax <= 0:
+                    raise DualIsUnboundedError  # :435-436
+            else:
+                self.optimum = True
+                break  # complementary slackness attained
+
+        x = np.zeros(n) if x_rp is None else x_rp[:n].copy()
+        basis = inner_basis[inner_basis < n]
+        cost = np.dot(self.c, x)  # :464
+        if expanded:
+            basis = basis[basis != n - 1]
+            x = x[:-1]
+        self.y = y.cpu().numpy()
+        return LinProgResult(x=x, basis=basis, cost=cost, iters=self.counter, optimum=self.optimum)

@@ -1,0 +1,223 @@
+"""Tableau-form primal simplex on the device, unpartitioned or column-partitioned over ranks.
+
+The tableau T = [B^-1 A | x_B ; rc | -z] stays in HBM and is updated in place by the streaming rank-1 kernel.
+This is the build's large-scale form of ``PrimalRevisedSimplexSolver`` (same pivot rules,
+primal_solvers.py:135-167; same result record); the reference has no tableau class of its own.
+
+Column partition (BASELINE.json config 4): rank g holds columns [col0, col0 + n_local) of the global matrix
+plus a replica of the x_B column.  Each pivot needs ONE collective: an all-gather of
+(local min rc, first owned negative column, that column of T) -- ``lpx_tableau_msg_len(m)`` doubles per rank.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .data_classes import LinProgResult
+from .device import roundup, stream_ptr, to_device, torch_cuda
+from .exceptions import BasisIsPrimalInfeasibleError, PrimalIsUnboundedError
+from .preprocessing import ProblemPreprocessingUtils
+
+
+class TableauEngine:
+    """Device state of one (slice of a) tableau."""
+
+    CHUNK = 64
+
+    def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
+                 group=None):
+        torch = torch_cuda()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.m, self.n = int(m), int(n_local)
+        self.col0 = int(col0)
+        self.n_global = self.n if n_global is None else int(n_global)
+        assert T.dtype == torch.float64 and T.is_cuda and T.is_contiguous() and T.shape[0] == m + 1
+        self.T = T
+        self.ld = T.shape[1]
+        self.basis = basis
+        self.var_state = var_state
+        self.c_global = c_global
+        self.ctrl = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        self.log_cap = int(log_cap)
+        self.log = torch.zeros((max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
+        ws = self.lib.lpx_tableau_workspace_bytes(self.m, self.n)
+        self.workspace = torch.zeros(ws, dtype=torch.uint8, device="cuda")
+        self.x = torch.zeros(self.n_global, dtype=torch.float64, device="cuda")
+        self.cost = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self.host_ctrl = _lib.LpxCtrl()
+        s = self.s = _lib.LpxTableau()
+        s.m, s.n, s.ld, s.col0, s.n_global = self.m, self.n, self.ld, self.col0, self.n_global
+        s.T, s.basis, s.var_state, s.ctrl = T.data_ptr(), basis.data_ptr(), var_state.data_ptr(), self.ctrl.data_ptr()
+        s.log = self.log.data_ptr() if self.log_cap > 0 else None
+        s.log_cap = self.log_cap
+        s.workspace, s.workspace_bytes = self.workspace.data_ptr(), ws
+        _lib.check(self.lib.lpx_ctrl_init(s.ctrl, int(f32_phase), stream_ptr()))
+        # column partition
+        self.group = group
+        self.nranks = 1
+        if group is not None:
+            import torch.distributed as dist
+
+            self.dist = dist
+            self.nranks = dist.get_world_size(group)
+            self.msg = int(self.lib.lpx_tableau_msg_len(self.m))
+            self.sendbuf = torch.zeros(self.msg, dtype=torch.float64, device="cuda")
+            self.recvbuf = torch.zeros(self.msg * self.nranks, dtype=torch.float64, device="cuda")
+            self._cpu_staging = dist.get_backend(group) == "gloo"
+
+    # ------------------------------------------------------------------ construction from a host problem
+    @classmethod
+    def from_columns(cls, A_cols32, b32, c32_global, basis, col0, n_global, inv32=None, bfs32=None, ld_align=2, **kw):
+        """Build the local slice from columns [col0, col0+n_local) of the float32 A (slack basis unless inv32)."""
+        torch = torch_cuda()
+        m, n_local = A_cols32.shape
+        ld = roundup(n_local + 1, ld_align)
+        T = torch.zeros((m + 1, ld), dtype=torch.float64, device="cuda")
+        A_dev = torch.from_numpy(np.ascontiguousarray(A_cols32)).to("cuda")
+        c_dev = to_device(np.asarray(c32_global, dtype=np.float32))
+        cb = np.asarray(c32_global, dtype=np.float32)[basis]
+        if inv32 is None:  # B = I: T = A, x_B = b, rc = c - c_B A
+            T[:m, :n_local].copy_(A_dev)
+            T[:m, n_local].copy_(to_device(np.asarray(b32, dtype=np.float64)))
+            rc = c_dev[col0:col0 + n_local].to(torch.float64)
+            if np.any(cb):
+                rc = rc - to_device(cb.astype(np.float64)) @ T[:m, :n_local]
+            T[m, :n_local].copy_(rc)
+            T[m, n_local] = -float(cb.astype(np.float64) @ np.asarray(b32, dtype=np.float64))
+        else:  # the reference's float32 starting state (primal_solvers.py:37-38, :64), carried as a tableau
+            inv_dev = to_device(np.asarray(inv32, dtype=np.float32))
+            T[:m, :n_local].copy_(inv_dev @ A_dev)
+            T[:m, n_local].copy_(to_device(np.asarray(bfs32, dtype=np.float64)))
+            y32 = to_device(cb.astype(np.float32)) @ inv_dev
+            T[m, :n_local].copy_(c_dev[col0:col0 + n_local] - y32 @ A_dev)
+            T[m, n_local] = -float(cb @ np.asarray(bfs32, dtype=np.float32))
+        del A_dev
+        basis_np = np.asarray(basis, dtype=np.int64)
+        var_state = np.full(n_local, _lib.VS_LOWER, dtype=np.int32)
+        loc = basis_np - col0
+        loc = loc[(loc >= 0) & (loc < n_local)]
+        var_state[loc] = _lib.VS_BASIC
+        vs_dev = to_device(var_state)
+        T[m, :n_local][vs_dev == _lib.VS_BASIC] = 0.0  # primal_solvers.py:65
+        return cls(T, m, n_local, to_device(basis_np), vs_dev, c_dev, col0=col0, n_global=n_global, **kw)
+
+    # ------------------------------------------------------------------ loop
+    def read_ctrl(self):
+        _lib.check(self.lib.lpx_read_ctrl(self.s.ctrl, C.byref(self.host_ctrl), stream_ptr()))
+        return self.host_ctrl
+
+    def enqueue(self, iters):
+        """Enqueue `iters` pivots without any host synchronisation."""
+        st = stream_ptr()
+        if self.group is None:
+            _lib.check(self.lib.lpx_tableau_iterate(C.byref(self.s), int(iters), st))
+            return
+        for _ in range(int(iters)):
+            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), self.sendbuf.data_ptr(), st))
+            self._all_gather()
+            _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), self.recvbuf.data_ptr(), self.nranks, st))
+
+    def _all_gather(self):
+        if self._cpu_staging:  # gloo rehearsal (CPU tests / 2 ranks on one GPU): stage through the host
+            send = self.sendbuf.cpu()
+            recv = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.recvbuf.copy_(recv)
+        else:  # RCCL over xGMI, stream-ordered with the kernels
+            self.dist.all_gather_into_tensor(self.recvbuf, self.sendbuf, group=self.group)
+
+    def run(self, maxiters):
+        st = stream_ptr()
+        _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
+        left = int(maxiters)
+        ctrl = None
+        while left > 0:
+            k = min(left, self.CHUNK)
+            self.enqueue(k)
+            left -= k
+            ctrl = self.read_ctrl()
+            if ctrl.status != _lib.RUNNING:
+                break
+        return ctrl if ctrl is not None else self.read_ctrl()
+
+    def expand(self):
+        _lib.check(self.lib.lpx_tableau_expand(C.byref(self.s), self.c_global.data_ptr(), self.x.data_ptr(),
+                                               self.cost.data_ptr(), stream_ptr()))
+        return self.x.cpu().numpy(), np.float64(self.cost.cpu().numpy()[0])
+
+    def host_basis(self):
+        return self.basis.cpu().numpy()
+
+    def host_log(self, count):
+        return self.log[: min(int(count), self.log_cap)].cpu().numpy()
+
+
+class PrimalTableauSimplexSolver:
+    """``PrimalRevisedSimplexSolver`` semantics on a carried tableau (constructor + solve() + LinProgResult).
+
+    ``group``: a torch.distributed process group => the tableau is column-partitioned over its ranks
+    (every rank passes the full problem or, with ``columns=(j0, j1)``, only its own column slice of A).
+    """
+
+    _LOG_CAP = 0
+
+    def __init__(self, c, A, b, basis, group=None, columns=None, n_global=None):
+        if columns is None:
+            self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
+            self.m, self.n = A32.shape
+            j0, j1 = 0, self.n
+            if group is not None:
+                import torch.distributed as dist
+
+                rank, size = dist.get_rank(group), dist.get_world_size(group)
+                j0, j1 = self.n * rank // size, self.n * (rank + 1) // size
+            A_cols = A32[:, j0:j1]
+        else:  # caller supplies only its slice (already float32, b >= 0): large problems
+            j0, j1 = columns
+            A_cols = np.asarray(A, dtype=np.float32)
+            self.c = np.asarray(c, dtype=np.float32)
+            self.b = np.asarray(b, dtype=np.float32)
+            if np.any(self.b < 0):
+                raise ValueError("column-slice construction needs b >= 0 (row flips need the whole matrix)")
+            self.m, self.n = A_cols.shape[0], int(n_global)
+            A32 = None
+        self.basis = np.array(basis).astype(int)
+        inv32 = bfs32 = None
+        k = self.n - self.m
+        slack = np.array_equal(self.basis, np.arange(k, self.n)) and self._slack_block_is_identity(A_cols, j0, j1, k)
+        if not slack:
+            if A32 is None:
+                raise ValueError("a non-slack starting basis needs the whole matrix")
+            inv32 = np.linalg.inv(A32[:, self.basis])  # primal_solvers.py:37
+            bfs32 = inv32 @ self.b
+        if not np.all((self.b if bfs32 is None else bfs32) >= 0.0):  # primal_solvers.py:43-48
+            raise BasisIsPrimalInfeasibleError
+        self.counter = None
+        self.optimum = None
+        self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
+                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group)
+
+    @staticmethod
+    def _slack_block_is_identity(A_cols, j0, j1, k):
+        lo, hi = max(j0, k), j1
+        if lo >= hi:
+            return True
+        blk = A_cols[:, lo - j0:hi - j0]
+        rows = np.arange(lo - k, hi - k)
+        return np.count_nonzero(blk) == hi - lo and np.all(blk[rows, np.arange(hi - lo)] == 1.0)
+
+    def solve(self, maxiters: int = 100):
+        self.counter = 0
+        self.optimum = False
+        ctrl = self._engine.run(maxiters)
+        self.counter = int(ctrl.counter)
+        self.basis[:] = self._engine.host_basis()
+        if ctrl.status == _lib.PRIMAL_UNBOUNDED:
+            raise PrimalIsUnboundedError
+        self.optimum = ctrl.status == _lib.OPTIMAL
+        x, cost = self._engine.expand()
+        return LinProgResult(x=x, basis=self.basis, cost=cost, iters=self.counter, optimum=self.optimum)
+
+    def pivot_log(self):
+        return self._engine.host_log(self._engine.read_ctrl().pivots)

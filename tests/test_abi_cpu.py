@@ -1,0 +1,75 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/lpx.h declares; host logic that needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests._util import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    import linprog_amd  # noqa: F401
+    from linprog_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "lpx.h")).read()
+    declared = set(re.findall(r"\b(lpx_[a-z0-9_]+)\s*\(", hdr))
+    L = _lib.load()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in lpx.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert L.lpx_version() == 1
+    assert C.sizeof(_lib.LpxCtrl) == 128
+    # size queries need no GPU
+    assert L.lpx_revised_workspace_bytes(64, 128) > 0 and L.lpx_tableau_workspace_bytes(1000, 2000) > 0
+    assert L.lpx_tableau_msg_len(1000) == 1004
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from linprog_amd.exceptions import LpxBackendError
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+
+    with pytest.raises(LpxBackendError):
+        PrimalRevisedSimplexSolver(np.array([0.0, 1.0]), np.array([[1.0, 1.0]]), np.array([1.0]), np.array([0]))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "linear-programming_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, re.M), f
+                assert not re.search(r"#include.*oracle|liblpx_oracle|dlopen", src), f
+
+
+def test_preprocessing_matches_reference_fixture():
+    """diet example: general form -> standard form -> bound rows; shapes and values pinned by SURVEY Appendix D."""
+    import json
+
+    from linprog_amd.preprocessing import ProblemPreprocessingUtils as P
+
+    cs = json.load(open(os.path.join(ROOT, "tests", "golden", "diet.json")))["cases"][0]
+    a = {k: np.array(v, dtype=float) for k, v in cs["arrays"].items()}
+    c, A, b = P.canonical_form_to_standard_form(a["c"], a["G"], a["h"])
+    assert A.shape == (4, 10) and A.dtype == np.float32 and (b >= 0).all()
+    lb = np.concatenate([a["lb"], np.zeros(4)])
+    ub = np.concatenate([a["ub"], np.full(4, np.inf)])
+    c1, A1, b1 = P.add_variables_bounds_to_coefficient_matrix(c, A, b, lb, ub)
+    assert A1.shape == (6, 12) and c1.shape == (12,)
+    assert A1[4, 4] == 1 and A1[4, 10] == -1 and b1[4] == np.float32(0.5)  # fish >= 0.5
+    assert A1[5, 1] == 1 and A1[5, 11] == 1 and b1[5] == 1.0               # milk <= 1
+
+
+def test_generators_are_partition_invariant():
+    from tests._util import gen
+
+    full = gen.gen_primal_columns(40, 100, 7, 0, 100)[0]
+    parts = np.hstack([gen.gen_primal_columns(40, 100, 7, j, min(j + 13, 100))[0] for j in range(0, 100, 13)])
+    assert np.array_equal(full, parts)
+    assert np.array_equal(full[:, 60:], np.eye(40, dtype=np.float32))

@@ -1,0 +1,128 @@
+"""GPU parity of the individually exported kernels (through the C ABI) against the oracle.
+
+Bar: bit-exact for the elementwise rank-1 update and the eta column (same fma rule as the oracle), exact
+indices and exact extreme values for every (value, index) reduction.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from linprog_amd import _lib
+    from oracle import oracle as O
+
+    L = _lib.load()
+    scratch = torch.zeros(int(L.lpx_reduce_scratch_bytes()), dtype=torch.uint8, device="cuda")
+    return dict(torch=torch, L=L, lib=_lib, O=O, scratch=scratch)
+
+
+def dev(env, a):
+    return env["torch"].from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1, 1, 1), (3, 9, 1), (64, 64, 0), (65, 129, 1), (257, 1000, 0),
+                                           (1001, 2001, 1), (2500, 777, 3)])
+def test_pivot_update_bit_exact(env, rows, cols, pad):
+    torch, L, O = env["torch"], env["L"], env["O"]
+    rng = np.random.default_rng(rows * 1000 + cols)
+    ld = cols + pad + ((cols + pad) % 2)
+    M = np.zeros((rows, ld))
+    M[:, :cols] = rng.standard_normal((rows, cols))
+    d = rng.standard_normal(rows)
+    r = int(rng.integers(rows))
+    e = O.eta(d, r)
+    want = O.rank1_update(M.copy(), r, e, cols=cols)
+    Md, ed = dev(env, M), dev(env, e)
+    scr = torch.zeros(ld + 2, dtype=torch.float64, device="cuda")
+    env["lib"].check(L.lpx_pivot_update(Md.data_ptr(), rows, cols, ld, r, ed.data_ptr(), scr.data_ptr(), None))
+    got = Md.cpu().numpy()
+    assert np.array_equal(got[:, :cols], want[:, :cols])
+    # eta column itself
+    dd, out = dev(env, d), torch.zeros(rows, dtype=torch.float64, device="cuda")
+    env["lib"].check(L.lpx_eta(dd.data_ptr(), rows, r, out.data_ptr(), None))
+    assert np.array_equal(out.cpu().numpy(), e)
+
+
+def test_pivot_update_rejects_bad_arguments(env):
+    L, torch = env["L"], env["torch"]
+    M = torch.zeros((4, 4), dtype=torch.float64, device="cuda")
+    e = torch.zeros(4, dtype=torch.float64, device="cuda")
+    assert L.lpx_pivot_update(M.data_ptr(), 4, 4, 3, 0, e.data_ptr(), e.data_ptr(), None) == -1  # ld < cols
+    assert L.lpx_pivot_update(M.data_ptr(), 4, 4, 4, 7, e.data_ptr(), e.data_ptr(), None) == -1  # r out of range
+    assert b"lpx_pivot_update" in L.lpx_last_error()
+
+
+def _outs(env):
+    t = env["torch"]
+    return t.zeros(2, dtype=t.float64, device="cuda"), t.zeros(2, dtype=t.int64, device="cuda")
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 257, 4097, 100003])
+def test_reductions_match_oracle(env, n):
+    L, O, lib = env["L"], env["O"], env["lib"]
+    rng = np.random.default_rng(n)
+    sp = env["scratch"].data_ptr()
+    for trial in range(4):
+        rc = rng.standard_normal(n)
+        if trial == 1:
+            rc = np.abs(rc)  # optimal: no negative entry
+        if trial == 2:
+            rc = np.round(rc, 1)  # many exact ties
+        if trial == 3:
+            rc[rng.integers(n)] = -1e-9  # inside the isclose band only
+            rc = np.where(rc < 0, rc, np.abs(rc))
+        vs = rng.integers(0, 4, n).astype(np.int32) if trial % 2 else None
+        ov, oi = _outs(env)
+        lib.check(L.lpx_price_first_negative(dev(env, rc).data_ptr(), None if vs is None else dev(env, vs).data_ptr(), n,
+                                            ov.data_ptr(), oi.data_ptr(), sp, None))
+        opt, mn, j = O.first_negative(rc, vs)
+        assert ov.cpu().numpy()[0] == mn and oi.cpu().numpy()[0] == j
+        lib.check(L.lpx_price_argmax(dev(env, rc).data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
+        _, mx, j = O.first_argmax(rc)
+        assert ov.cpu().numpy()[0] == mx and oi.cpu().numpy()[0] == j
+        # ratio tests (float64 and the float32 first-iteration variant)
+        x = np.abs(rng.standard_normal(n)).astype(np.float32).astype(np.float64)
+        d = np.round(rng.standard_normal(n), 2 if trial == 2 else 6).astype(np.float32).astype(np.float64)
+        for f32 in (0, 1):
+            lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), n, f32, ov.data_ptr(),
+                                         oi.data_ptr(), sp, None))
+            r, th, dm = O.ratio_primal(x, d, f32)
+            v = ov.cpu().numpy()
+            assert oi.cpu().numpy()[0] == r and v[0] == th and v[1] == dm
+            lib.check(L.lpx_ratio_dual(dev(env, x).data_ptr(), dev(env, d).data_ptr(),
+                                       None if vs is None else dev(env, vs).data_ptr(), n, f32, ov.data_ptr(),
+                                       oi.data_ptr(), sp, None))
+            j, th, rm = O.ratio_dual(x, d, f32, vs)
+            v = ov.cpu().numpy()
+            if vs is None or np.any(vs != 3):
+                assert oi.cpu().numpy()[0] == j and v[0] == th and v[1] == rm
+        lbB = x - np.abs(rng.standard_normal(n))
+        ubB = x + np.abs(rng.standard_normal(n))
+        for sign in (1.0, -1.0):
+            lib.check(L.lpx_ratio_bounded(dev(env, x).data_ptr(), dev(env, d).data_ptr(), dev(env, lbB).data_ptr(),
+                                          dev(env, ubB).data_ptr(), n, sign, ov.data_ptr(), oi.data_ptr(), sp, None))
+            g1, r1, g2, r2 = O.ratio_bounded(x, d, lbB, ubB, sign)
+            assert ov.cpu().numpy().tolist() == [g1, g2] and oi.cpu().numpy().tolist() == [r1, r2]
+        lib.check(L.lpx_dual_row_select(dev(env, rc).data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
+        opt, mn, j = O.first_negative(rc)
+        assert ov.cpu().numpy()[0] == mn and oi.cpu().numpy()[0] == j
+
+
+def test_float32_ratio_tie_breaks_like_reference(env):
+    """Two float64 quotients that round to the same float32 must tie (lowest index wins) in the f32 phase."""
+    L, lib = env["L"], env["lib"]
+    x = np.array([1.0 + 2.0 ** -30, 1.0])
+    d = np.array([3.0, 3.0])
+    ov, oi = _outs(env)
+    sp = env["scratch"].data_ptr()
+    lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), 2, 1, ov.data_ptr(), oi.data_ptr(), sp, None))
+    assert oi.cpu().numpy()[0] == 0
+    lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), 2, 0, ov.data_ptr(), oi.data_ptr(), sp, None))
+    assert oi.cpu().numpy()[0] == 1

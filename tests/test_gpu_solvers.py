@@ -1,0 +1,191 @@
+"""GPU parity of the solver classes (drop-in boundary) against the reference's golden vectors and the oracle.
+
+Reads like the reference's own tests (tests/test_*_solvers.py there): same constructors, ``solve()``, result
+fields.  Bar: identical pivot triples / basis / iters / optimum / exception; x and cost within 1e-9 relative.
+"""
+import numpy as np
+import pytest
+
+from tests._util import assert_close, case_id, gen, load, problem_of, ub_of
+
+pytestmark = pytest.mark.gpu
+
+BASE = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json")
+        if cs["solver"] in ("PrimalRevisedSimplexSolver", "DualRevisedSimplexSolver")]
+
+
+def logged(cls, cap=8192):
+    return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
+
+
+def solver_class(name):
+    from linprog_amd import dual_solvers, primal_solvers, special_solvers
+
+    for mod in (primal_solvers, dual_solvers, special_solvers):
+        if hasattr(mod, name):
+            return getattr(mod, name)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("cs", BASE, ids=case_id)
+def test_base_solvers_match_reference(cs):
+    from linprog_amd import exceptions
+
+    ref = cs["ref"]
+    cls = logged(solver_class(cs["solver"]), cap=max(16, len(ref["pivots"]) + 1))
+    c, A, b, basis = problem_of(cs)
+    if ref["exception"] in ("BasisIsPrimalInfeasibleError", "BasisIsDualInfeasibleError"):
+        with pytest.raises(getattr(exceptions, ref["exception"])):
+            cls(c, A, b, basis)
+        return
+    s = cls(c, A, b, basis)
+    if ref["exception"]:
+        with pytest.raises(getattr(exceptions, ref["exception"])):
+            s.solve(cs.get("maxiters", 100))
+        assert s.pivot_log().tolist() == ref["pivots"]
+        return
+    res = s.solve(cs.get("maxiters", 100))
+    assert s.pivot_log().tolist() == ref["pivots"], "pivot sequence differs from the reference"
+    assert res.iters == ref["iters"]
+    assert res.optimum == ref["optimum"]
+    assert res.basis.tolist() == ref["basis"]
+    assert res.basis is s.basis  # result aliases solver state (primal_solvers.py:83-86)
+    if "x" in ref:
+        assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+    if "optimal_basis" in cs:  # the reference's own assertion (tests/test_primal_base_solvers.py:19-21)
+        assert np.linalg.norm(res.x[res.basis] - np.array(cs["optimal_bfs"]), 2) < 1e-2
+        assert np.array_equal(res.basis, cs["optimal_basis"])
+
+
+@pytest.mark.parametrize("name", ["PrimalRevisedSimplexSolver"])
+def test_blands_sequence_reentrant(name):
+    """tests/test_primal_base_solvers.py:24-34 of the reference."""
+    cs = [c for c in load("textbook.json") if c["problem"] == "primal_solver_blands_sequence_problem1"
+          and c["solver"] == name][0]
+    c, A, b, basis = problem_of(cs)
+    s = solver_class(name)(c, A, b, basis)
+    path = []
+    for want in cs["basis_seq"][1:]:
+        res = s.solve(maxiters=1)
+        path.append(np.array_equal(want, res.basis) and res.iters == 1 and res.optimum is False)
+    res = s.solve(maxiters=1)
+    path.append(np.array_equal(cs["basis_seq"][-1], res.basis) and res.optimum is True)
+    assert all(path)
+
+
+def test_attributes_and_external_pivot():
+    """What PhaseOneSimplexSolver reads from a solver (special_solvers.py:69-80)."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(16, 32, 5)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    o = O.OracleRevised(c, A, b, basis)
+    assert s.inv_basis_matrix.dtype == np.float32 and s.bfs.dtype == np.float32  # Appendix B, before any pivot
+    s.pivot(3, 5)
+    o.pivot(3, 5)
+    assert s.basis[3] == 5
+    assert s.inv_basis_matrix.dtype == np.float64
+    assert_close(s.inv_basis_matrix, o.Binv, "B^-1 after pivot()")
+    assert_close(s.bfs, o.xB, "bfs after pivot()")
+    res = s._get_solver_return_object()
+    assert_close(res.x, O.expand_and_cost(o.xB, o.basis, o.c, 32)[0], "x")
+
+
+@pytest.mark.parametrize("cs", [c for c in load("textbook.json") if c["solver"] == "BoundedVariablePrimalSimplexSolver"]
+                         + load("bounded.json"), ids=case_id)
+def test_bounded_matches_reference(cs):
+    from linprog_amd.special_solvers import BoundedVariablePrimalSimplexSolver
+
+    ref = cs["ref"]
+    if "gen" in cs:
+        c, A, b, lb, ub, basis, lbn, ubn = gen.gen_box(cs["m"], cs["n"], cs["seed"])
+    else:
+        c, A, b, lb, ub = np.array(cs["c"]), np.array(cs["A"]), np.array(cs["b"]), np.array(cs["lb"]), ub_of(cs)
+        basis, lbn, ubn = cs["basis"], cs["lb_nonbasic"], cs["ub_nonbasic"]
+    s = logged(BoundedVariablePrimalSimplexSolver)(c, A, b, lb, ub, basis, lbn, ubn)
+    res = s.solve(100000)
+    assert res.optimum is True
+    assert res.iters == ref["iters_total"]
+    assert s.pivot_log().tolist() == [e[:3] for e in ref["steps"]]
+    assert res.basis.tolist() == ref["basis"]
+    assert s.ub_nonbasic_vars.tolist() == ref["ub_nonbasic_final"]
+    assert s.lb_nonbasic_vars.tolist() == ref["lb_nonbasic_final"]
+    assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+    with pytest.raises(NotImplementedError):
+        s.pivot(0, 0)
+
+
+@pytest.mark.parametrize("cs", [c for c in load("textbook.json") if c["solver"] == "PrimalDualAlgorithm"]
+                         + load("primal_dual.json"), ids=case_id)
+def test_primal_dual_matches_reference(cs):
+    from linprog_amd.special_solvers import PrimalDualAlgorithm
+
+    ref = cs["ref"]
+    if "gen" in cs:
+        c, A, b, _ = gen.gen_dual(cs["m"], cs["n"], cs["seed"])
+    else:
+        c, A, b = np.array(cs["c"]), np.array(cs["A"]), np.array(cs["b"])
+    s = logged(PrimalDualAlgorithm, cap=4096)(c, A, b)
+    res = s.solve(100000, 100000)
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"]
+    n = s.n
+    flat = []  # map [A | I] numbering to the reference's compacted restricted-primal numbering
+    for adm, lg in zip(s.admissible_sets, s.inner_pivot_logs):
+        pos = {int(col): k for k, col in enumerate(adm)}
+        k = len(adm)
+        for row, ent, lv in lg.tolist():
+            flat.append([row, pos[ent] if ent < n else k + ent - n, pos[lv] if lv < n else k + lv - n])
+    assert flat == ref["pivots"]
+    assert res.basis.tolist() == ref["basis"]
+    assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+    if "optimal_bfs" in cs:  # tests/test_primal_dual_algorithm.py:11-16: exact
+        assert np.array_equal(res.x, np.array(cs["optimal_bfs"], dtype=float))
+
+
+@pytest.mark.parametrize("cs", [c for c in load("textbook.json") if c["solver"] == "SimplexSolver"] + load("diet.json"),
+                         ids=case_id)
+def test_two_phase_driver(cs):
+    from linprog_amd import exceptions
+    from linprog_amd.simplex import SimplexSolver
+
+    ref = cs["ref"]
+    if cs["problem"] == "diet":
+        a = {k: np.array(v, dtype=float) for k, v in cs["arrays"].items()}
+        solver = SimplexSolver(c=a["c"], G=a["G"], h=a["h"], lb=a["lb"], ub=a["ub"])
+    else:
+        solver = SimplexSolver(np.array(cs["c"]), np.array(cs["A"]), np.array(cs["b"]))
+    if ref["exception"]:
+        with pytest.raises(getattr(exceptions, ref["exception"])):
+            solver.solve()
+        return
+    res = solver.solve()
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"] and res.basis is None
+    assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 (m=1000, n=2000): size-independent properties of a pivot window, plus the oracle's
+    pivot sequence on the same window."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(1000, 2000, 0)
+    K = 150
+    s = logged(PrimalRevisedSimplexSolver, cap=K)(c, A, b, basis)
+    res = s.solve(K)
+    o = O.OracleRevised(c, A, b, basis, log_cap=K).solve(K)
+    assert s.pivot_log().tolist() == o.log.tolist()
+    assert res.iters == K and res.optimum is False
+    A32 = s.A.astype(np.float64)
+    # B^-1 B = I, A x = b, x >= 0, cost = c.x, basis entries distinct
+    Binv = s.inv_basis_matrix
+    assert np.abs(Binv @ A32[:, res.basis] - np.eye(1000)).max() < 1e-9
+    assert np.abs(A32 @ res.x - s.b).max() < 1e-9
+    assert res.x.min() >= -1e-12 and len(set(res.basis.tolist())) == 1000
+    assert_close(res.cost, o.cost, "cost")
+    assert_close(res.x, o.x, "x")

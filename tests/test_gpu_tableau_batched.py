@@ -1,0 +1,111 @@
+"""GPU parity of the tableau-form solver and the batched small-LP kernel."""
+import numpy as np
+import pytest
+
+from tests._util import assert_close, case_id, gen, load, problem_of
+
+pytestmark = pytest.mark.gpu
+
+PRIMAL = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json")
+          if cs["solver"] == "PrimalRevisedSimplexSolver" and not cs["ref"]["exception"]]
+
+
+def logged(cls, cap):
+    return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
+
+
+@pytest.mark.parametrize("cs", PRIMAL, ids=case_id)
+def test_tableau_matches_reference(cs):
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    ref = cs["ref"]
+    c, A, b, basis = problem_of(cs)
+    s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis)
+    res = s.solve(cs.get("maxiters", 100))
+    assert s.pivot_log().tolist() == ref["pivots"]
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"] and res.basis.tolist() == ref["basis"]
+    if "x" in ref:
+        assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+
+
+def test_tableau_bit_exact_vs_oracle():
+    """Elementwise path (no reductions over floating-point sums): the carried tableau must be bit-identical."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(96, 200, 11)
+    s = PrimalTableauSimplexSolver(c, A, b, basis)
+    o = O.OracleTableau(c, A, b, basis)
+    for k in (1, 7, 40):
+        s.solve(k)
+        o.solve(k)
+        T = s._engine.T.cpu().numpy()
+        assert np.array_equal(T[:, :201], o.T[:, :201])
+
+
+def test_tableau_unbounded_and_infeasible_start():
+    from linprog_amd import exceptions
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    c, A, b, basis = gen.gen_primal(8, 16, 0)
+    A[:, :8] *= -1
+    with pytest.raises(exceptions.PrimalIsUnboundedError):
+        PrimalTableauSimplexSolver(c, A, b, basis).solve()
+    c, A, b, basis = gen.gen_dual(8, 16, 0)
+    with pytest.raises(exceptions.BasisIsPrimalInfeasibleError):
+        PrimalTableauSimplexSolver(c, A, b, basis)
+
+
+def test_batched_bit_identical_to_oracle_and_reference_sequences():
+    """Config 3 shape (m=64, n=128): every LP's pivot log equals the oracle's, x/cost bit-identical; the LPs
+    that have a golden also equal the reference's sequence."""
+    from linprog_amd.batched import BatchedPrimalSolver
+    from oracle import oracle as O
+
+    seeds = list(range(24))
+    probs = [gen.gen_primal(64, 128, s) for s in seeds]
+    c = np.stack([p[0] for p in probs]); A = np.stack([p[1] for p in probs])
+    b = np.stack([p[2] for p in probs]); basis = np.stack([p[3] for p in probs])
+    solver = BatchedPrimalSolver(c, A, b, basis, log_cap=1024)
+    res = solver.solve(100000)
+    logs = solver.pivot_logs()
+    golden = {cs["seed"]: cs["ref"] for cs in load("random.json")
+              if cs.get("gen") == "gen_primal" and cs["m"] == 64 and cs["n"] == 128 and cs["maxiters"] == 100000
+              and cs["solver"] == "PrimalRevisedSimplexSolver"}
+    for i, s in enumerate(seeds):
+        o = O.OracleRevised(*probs[i], log_cap=1024).solve(100000)
+        assert logs[i].tolist() == o.log.tolist()
+        assert res[i].optimum and res[i].iters == o.iters
+        assert np.array_equal(res[i].x, o.x) and res[i].cost == o.cost
+        assert res[i].basis.tolist() == o.basis.tolist()
+        if s in golden:
+            assert logs[i].tolist() == golden[s]["pivots"]
+            assert_close(res[i].x, golden[s]["x"], "x")
+            assert_close(res[i].cost, golden[s]["cost"], "cost")
+
+
+@pytest.mark.parametrize("m,n", [(4, 8), (16, 32), (32, 64), (48, 160)])
+def test_batched_other_shapes_and_limits(m, n):
+    from linprog_amd.batched import BatchedPrimalSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_primal(m, n, s) for s in range(6)]
+    solver = BatchedPrimalSolver(*[np.stack([p[k] for p in probs]) for k in range(4)], log_cap=512)
+    res = solver.solve(30)  # some hit the iteration limit: optimum False, iters == 30
+    for i, p in enumerate(probs):
+        o = O.OracleRevised(*p, log_cap=512).solve(30)
+        assert solver.pivot_logs()[i].tolist() == o.log.tolist()
+        assert res[i].iters == o.iters and res[i].optimum == (o.status == O.OPTIMAL)
+        assert np.array_equal(res[i].x, o.x)
+
+
+def test_batched_rejects_oversize():
+    from linprog_amd import _lib
+    from linprog_amd.batched import BatchedPrimalSolver
+    from linprog_amd.exceptions import LpxBackendError
+
+    probs = [gen.gen_primal(130, 260, 0)]
+    solver = BatchedPrimalSolver(*[np.stack([p[k] for p in probs]) for k in range(4)])
+    with pytest.raises(LpxBackendError):
+        solver.solve(10)
