@@ -95,6 +95,10 @@ def load():
     """Load liblpx.so once; raise LpxBackendError (never fall back) when it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own HIP runtime; it must be the one already in the process when liblpx's
+        # libamdhip64 dependency is resolved, or the two would not share device state.
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise LpxBackendError(
                 f"{LIB_PATH} not found: build it with `make -C linear-programming_amd/csrc` "

@@ -80,37 +80,39 @@ def test_reductions_match_oracle(env, n):
             rc = np.where(rc < 0, rc, np.abs(rc))
         vs = rng.integers(0, 4, n).astype(np.int32) if trial % 2 else None
         ov, oi = _outs(env)
-        lib.check(L.lpx_price_first_negative(dev(env, rc).data_ptr(), None if vs is None else dev(env, vs).data_ptr(), n,
-                                            ov.data_ptr(), oi.data_ptr(), sp, None))
+        # keep every device tensor referenced while kernels use it (temporaries would be recycled)
+        rc_d = dev(env, rc)
+        vs_d = None if vs is None else dev(env, vs)
+        vs_p = None if vs is None else vs_d.data_ptr()
+        lib.check(L.lpx_price_first_negative(rc_d.data_ptr(), vs_p, n, ov.data_ptr(), oi.data_ptr(), sp, None))
         opt, mn, j = O.first_negative(rc, vs)
         assert ov.cpu().numpy()[0] == mn and oi.cpu().numpy()[0] == j
-        lib.check(L.lpx_price_argmax(dev(env, rc).data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
+        lib.check(L.lpx_price_argmax(rc_d.data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
         _, mx, j = O.first_argmax(rc)
         assert ov.cpu().numpy()[0] == mx and oi.cpu().numpy()[0] == j
         # ratio tests (float64 and the float32 first-iteration variant)
         x = np.abs(rng.standard_normal(n)).astype(np.float32).astype(np.float64)
         d = np.round(rng.standard_normal(n), 2 if trial == 2 else 6).astype(np.float32).astype(np.float64)
+        x_d, d_d = dev(env, x), dev(env, d)
         for f32 in (0, 1):
-            lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), n, f32, ov.data_ptr(),
-                                         oi.data_ptr(), sp, None))
+            lib.check(L.lpx_ratio_primal(x_d.data_ptr(), d_d.data_ptr(), n, f32, ov.data_ptr(), oi.data_ptr(), sp, None))
             r, th, dm = O.ratio_primal(x, d, f32)
             v = ov.cpu().numpy()
             assert oi.cpu().numpy()[0] == r and v[0] == th and v[1] == dm
-            lib.check(L.lpx_ratio_dual(dev(env, x).data_ptr(), dev(env, d).data_ptr(),
-                                       None if vs is None else dev(env, vs).data_ptr(), n, f32, ov.data_ptr(),
-                                       oi.data_ptr(), sp, None))
+            lib.check(L.lpx_ratio_dual(x_d.data_ptr(), d_d.data_ptr(), vs_p, n, f32, ov.data_ptr(), oi.data_ptr(), sp, None))
             j, th, rm = O.ratio_dual(x, d, f32, vs)
             v = ov.cpu().numpy()
             if vs is None or np.any(vs != 3):
                 assert oi.cpu().numpy()[0] == j and v[0] == th and v[1] == rm
         lbB = x - np.abs(rng.standard_normal(n))
         ubB = x + np.abs(rng.standard_normal(n))
+        lb_d, ub_d = dev(env, lbB), dev(env, ubB)
         for sign in (1.0, -1.0):
-            lib.check(L.lpx_ratio_bounded(dev(env, x).data_ptr(), dev(env, d).data_ptr(), dev(env, lbB).data_ptr(),
-                                          dev(env, ubB).data_ptr(), n, sign, ov.data_ptr(), oi.data_ptr(), sp, None))
+            lib.check(L.lpx_ratio_bounded(x_d.data_ptr(), d_d.data_ptr(), lb_d.data_ptr(), ub_d.data_ptr(), n, sign,
+                                          ov.data_ptr(), oi.data_ptr(), sp, None))
             g1, r1, g2, r2 = O.ratio_bounded(x, d, lbB, ubB, sign)
             assert ov.cpu().numpy().tolist() == [g1, g2] and oi.cpu().numpy().tolist() == [r1, r2]
-        lib.check(L.lpx_dual_row_select(dev(env, rc).data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
+        lib.check(L.lpx_dual_row_select(rc_d.data_ptr(), n, ov.data_ptr(), oi.data_ptr(), sp, None))
         opt, mn, j = O.first_negative(rc)
         assert ov.cpu().numpy()[0] == mn and oi.cpu().numpy()[0] == j
 
@@ -122,7 +124,8 @@ def test_float32_ratio_tie_breaks_like_reference(env):
     d = np.array([3.0, 3.0])
     ov, oi = _outs(env)
     sp = env["scratch"].data_ptr()
-    lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), 2, 1, ov.data_ptr(), oi.data_ptr(), sp, None))
+    x_d, d_d = dev(env, x), dev(env, d)
+    lib.check(L.lpx_ratio_primal(x_d.data_ptr(), d_d.data_ptr(), 2, 1, ov.data_ptr(), oi.data_ptr(), sp, None))
     assert oi.cpu().numpy()[0] == 0
-    lib.check(L.lpx_ratio_primal(dev(env, x).data_ptr(), dev(env, d).data_ptr(), 2, 0, ov.data_ptr(), oi.data_ptr(), sp, None))
+    lib.check(L.lpx_ratio_primal(x_d.data_ptr(), d_d.data_ptr(), 2, 0, ov.data_ptr(), oi.data_ptr(), sp, None))
     assert oi.cpu().numpy()[0] == 1
