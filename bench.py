@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X simplex pivot path (contract: see the task / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tableau|tableau1k|batch]
+
+A "step" is one simplex pivot (pricing scan -> column gather + ratio test -> eta/prepare -> rank-1 update) of
+the tableau-form loop on BASELINE.json's metric configuration: gen_primal_columns(m=20000, n=40000, seed 0),
+fp64 tableau (20001 x 40001 doubles = 6.4 GB) resident in HBM, slack starting basis.  N=1: unpartitioned.
+N>1: the tableau is column-partitioned over the N ranks (one process per GPU, torch.distributed / RCCL) and
+every pivot does one all-gather of the ranks' proposals ("scaling": "strong", total work fixed).
+The K timed pivots are enqueued back to back with no host synchronisation.
+
+Rank 0 prints ONE JSON line with `roofline` (K1 = rank-1 update kernel, HIP events on the launch stream) and,
+at N=1, `cpu_baseline` (the oracle's tableau loop on the host cores over a bounded number of pivots of the
+same workload; its pivot log is also the parity check of the GPU run's first pivots).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch"])
+    ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import linprog_amd  # noqa: F401
+    from linprog_amd import _lib, problems
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    if args.workload == "batch":
+        return bench_batch(args, rank, world, group)
+
+    m, n = (20000, 40000) if args.workload == "tableau" else (1000, 2000)
+    K, W = args.steps, args.warmup
+    j0, j1 = n * rank // world, n * (rank + 1) // world
+    t_setup = time.time()
+    A_cols, b, c, basis = problems.gen_primal_columns(m, n, args.seed, j0, j1)
+    Solver = type("BenchTableau", (PrimalTableauSimplexSolver,), {"_LOG_CAP": W + K + 8})
+    solver = Solver(c, A_cols, b, basis, group=group, columns=(j0, j1), n_global=n)
+    eng = solver._engine
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, torch.cuda.current_stream().cuda_stream))
+    eng.enqueue(W)
+    barrier()
+    _lib.check(lib.lpx_profile_k1(1))
+    barrier()
+    t0 = time.perf_counter()
+    eng.enqueue(K)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    import ctypes as C
+
+    k1_ms, k1_n = C.c_double(), C.c_int64()
+    _lib.check(lib.lpx_profile_k1_read(C.byref(k1_ms), C.byref(k1_n)))
+    _lib.check(lib.lpx_profile_k1(0))
+    ctrl = eng.read_ctrl()
+    pivots_done = int(ctrl.pivots)
+    if pivots_done != W + K or ctrl.status != _lib.RUNNING:
+        sys.exit(f"bench invalid: {pivots_done} pivots done of {W + K}, status {ctrl.status}")
+
+    # roofline of K1 on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
+    n_loc = j1 - j0
+    bytes_per_launch = 16.0 * (m + 1) * (n_loc + 1)
+    k1_avg_s = (k1_ms.value / 1e3) / max(1, k1_n.value)
+    achieved = bytes_per_launch / k1_avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    if os.path.exists(tpath) and args.workload == "tableau" and world == 1:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "simplex pivots/sec (20000x40000 fp64 tableau)" if args.workload == "tableau"
+        else "simplex pivots/sec (1000x2000 fp64 tableau)",
+        "value": K / dt,
+        "unit": "pivots/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"gen_primal_columns(m={m}, n={n}, seed={args.seed}) dense primal tableau simplex, "
+                               f"slack start, first-negative-index pricing",
+                   "m": m, "n": n, "form": "tableau", "partition": f"columns/{world}",
+                   "setup_s": round(t_setup, 2)},
+        "roofline": {"bound": "hbm", "kernel": "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1_avg_s * 1e3, "launches": k1_n.value,
+                     "whole_pivot_GBs": 16.0 * (m + 1) * (n + 1) * K / dt / 1e9},
+    }
+    if rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, m, n, A_cols, b, c, basis, solver)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, m, n, A, b, c, basis, solver):
+    """Oracle tableau loop (C, OpenMP) on the host cores, bounded sample; also the parity gate of the timed run."""
+    from oracle import oracle as O
+
+    cores = min(16, os.cpu_count() or 1)
+    kc = args.cpu_pivots
+    if kc is None:
+        kc = 12 if m >= 10000 else 400
+    if kc <= 0:
+        return None
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    o = O.OracleTableau(c, A, b, basis, log_cap=kc + 1, threads=cores, ld=n + 1 + ((n + 1) % 2))
+    t0 = time.perf_counter()
+    r = o.solve(kc)
+    dt = time.perf_counter() - t0
+    gpu_log = solver.pivot_log()[:kc].tolist()
+    if r.log.tolist() != gpu_log:
+        sys.exit("bench invalid: GPU pivot sequence differs from the oracle's on the same workload")
+    return {"value": kc / dt, "unit": "pivots/s", "cores": cores, "kind": "port",
+            "sample": f"first {kc} pivots of the same workload, oracle tableau loop (C + OpenMP rank-1 update)",
+            "parity": f"GPU and oracle (row, entering, leaving) sequences identical on these {kc} pivots"}
+
+
+def bench_batch(args, rank, world, group):
+    """Config 3: 4096 x gen_primal(64, 128, seed) full solves, sharded by LP index (weak: per-GPU count fixed)."""
+    import torch
+    import torch.distributed as dist
+
+    from linprog_amd import problems
+    from linprog_amd.batched import BatchedPrimalSolver
+
+    per_gpu = 4096
+    seeds = range(rank * per_gpu, (rank + 1) * per_gpu)
+    probs = [problems.gen_primal(64, 128, s) for s in seeds]
+    solver = BatchedPrimalSolver(*[np.stack([p[k] for p in probs]) for k in range(4)])
+    basis0 = solver.basis.clone()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.basis.copy_(basis0)
+        solver.enqueue(100000)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.basis.copy_(basis0)
+        solver.enqueue(100000)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    piv = int(solver.pivots.sum().item())
+    ok = bool((solver.status == 1).all().item())
+    out = {"metric": "batched LPs solved/sec (m=64 n=128)", "value": per_gpu * world * args.steps / dt, "unit": "LPs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "4096 x gen_primal(64,128,seed) per GPU, full solves, one workgroup per LP",
+                      "pivots_per_step_per_gpu": piv, "all_optimal": ok},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "note": "LDS-resident; pivots/s = %.3e" % (piv * world * args.steps / dt)}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

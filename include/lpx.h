@@ -123,6 +123,12 @@ int lpx_ctrl_begin_solve(lpx_ctrl *dev_ctrl, void *stream);
 /* Copy the control block to the host and synchronise the stream: the "scalar status flag" round trip. */
 int lpx_read_ctrl(const lpx_ctrl *dev_ctrl, lpx_ctrl *host_ctrl, void *stream);
 
+/* Measurement hooks (no counterpart in the reference): while enabled, HIP events are recorded on the launch
+ * stream around every launch of the rank-1 pivot-update kernel (at most 4096 launches are kept).
+ * lpx_profile_k1_read synchronises on them and returns the summed kernel time and the launch count. */
+int lpx_profile_k1(int enable);
+int lpx_profile_k1_read(double *total_ms, int64_t *launches);
+
 /* ------------------------------------------------------------------------------ revised-form solver loop */
 int64_t lpx_revised_workspace_bytes(int64_t m, int64_t n);
 
@@ -184,7 +190,7 @@ int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A
 
 /* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
 /* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:
- * _update_inv_basis_matrix / _update_bfs, primal_solvers.py:247-253.  rowr_scratch: >= cols doubles. */
+ * _update_inv_basis_matrix / _update_bfs, primal_solvers.py:247-253.  rowr_scratch: >= ld doubles. */
 int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
                      double *rowr_scratch, void *stream);
 /* Eta column, primal_solvers.py:235-244: e_i = (-d_i)/d_r, e_r = 1/d_r. */

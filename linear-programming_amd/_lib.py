@@ -60,6 +60,8 @@ _SIGS = {
     "lpx_ctrl_init": (C.c_int, [vp, C.c_int32, vp]),
     "lpx_ctrl_begin_solve": (C.c_int, [vp, vp]),
     "lpx_read_ctrl": (C.c_int, [vp, C.POINTER(LpxCtrl), vp]),
+    "lpx_profile_k1": (C.c_int, [C.c_int]),
+    "lpx_profile_k1_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
     "lpx_revised_workspace_bytes": (i64, [i64, i64]),
     "lpx_revised_iterate": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
     "lpx_revised_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),

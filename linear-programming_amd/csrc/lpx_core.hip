@@ -29,6 +29,44 @@ extern "C" const char *lpx_last_error(void) { return g_err; }
 extern "C" int lpx_version(void) { return LPX_VERSION; }
 
 // ---------------------------------------------------------------------------------------------------------
+// K1 timing hooks
+// ---------------------------------------------------------------------------------------------------------
+LpxK1Profile &lpx_k1_profile()
+{
+    static LpxK1Profile p;
+    return p;
+}
+extern "C" int lpx_profile_k1(int enable)
+{
+    LpxK1Profile &p = lpx_k1_profile();
+    if (enable && !p.created) {
+        for (int i = 0; i < LPX_PROF_CAP; ++i) {
+            LPX_HIP(hipEventCreate(&p.start[i]));
+            LPX_HIP(hipEventCreate(&p.stop[i]));
+        }
+        p.created = true;
+    }
+    p.enabled = enable != 0;
+    p.count = 0;
+    return LPX_OK;
+}
+extern "C" int lpx_profile_k1_read(double *total_ms, int64_t *launches)
+{
+    LPX_REQUIRE(total_ms && launches, "null output");
+    LpxK1Profile &p = lpx_k1_profile();
+    double tot = 0.0;
+    for (int64_t i = 0; i < p.count; ++i) {
+        LPX_HIP(hipEventSynchronize(p.stop[i]));
+        float ms = 0.f;
+        LPX_HIP(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p.count;
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // workspace layout (pure function of m, n)
 // ---------------------------------------------------------------------------------------------------------
 struct ColsumPlan {
@@ -758,7 +796,9 @@ static void launch_update(const lpx_revised *s, const RevisedWs &w, bool update_
     a.ctrl = s->ctrl; a.xB = update_xB ? s->xB : nullptr; a.xr_old = w.scal; a.col0 = 0;
     const Rank1Plan p = lpx_rank1_plan(s->m, s->m);
     a.rows_per_block = p.rows_per_block;
+    lpx_k1_begin(st);
     hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_k1_end(st);
 }
 static void launch_bounded_bfs(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
 {
@@ -1012,8 +1052,10 @@ extern "C" int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t l
     a.M = M; a.rows = rows; a.cols = cols; a.ld = ld; a.e = e; a.rowr = rowr_scratch; a.r = r; a.ctrl = nullptr;
     const Rank1Plan p = lpx_rank1_plan(rows, cols);
     a.rows_per_block = p.rows_per_block;
+    lpx_k1_begin(st);
     if (rank1_use_nt()) hipLaunchKernelGGL((k_rank1<false, true>), p.grid, dim3(LPX_BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_k1_end(st);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

@@ -129,3 +129,30 @@ static inline Rank1Plan lpx_rank1_plan(int64_t rows, int64_t cols)
     p.grid = dim3((unsigned)nstrips, (unsigned)lpx_cdiv(rows, rpb), 1);
     return p;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// K1 timing hooks (bench.py roofline): HIP events recorded on the launch stream around every K1 launch while
+// enabled.  Events are created once by lpx_profile_k1(1); recording them allocates nothing.
+// ---------------------------------------------------------------------------------------------------------
+#define LPX_PROF_CAP 4096
+struct LpxK1Profile {
+    bool enabled = false;
+    bool created = false;
+    int64_t count = 0;
+    hipEvent_t start[LPX_PROF_CAP];
+    hipEvent_t stop[LPX_PROF_CAP];
+};
+LpxK1Profile &lpx_k1_profile();
+static inline void lpx_k1_begin(hipStream_t st)
+{
+    LpxK1Profile &p = lpx_k1_profile();
+    if (p.enabled && p.count < LPX_PROF_CAP) (void)hipEventRecord(p.start[p.count], st);
+}
+static inline void lpx_k1_end(hipStream_t st)
+{
+    LpxK1Profile &p = lpx_k1_profile();
+    if (p.enabled && p.count < LPX_PROF_CAP) {
+        (void)hipEventRecord(p.stop[p.count], st);
+        p.count += 1;
+    }
+}

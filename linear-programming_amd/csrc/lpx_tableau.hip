@@ -262,8 +262,10 @@ static void t_launch_update(const lpx_tableau *s, const TabWs &w, hipStream_t st
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
     const Rank1Plan p = lpx_rank1_plan(a.rows, a.cols);
     a.rows_per_block = p.rows_per_block;
+    lpx_k1_begin(st);
     if (t_use_nt()) hipLaunchKernelGGL((k_rank1<true, true>), p.grid, dim3(LPX_BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_rank1<true, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_k1_end(st);
 }
 
 extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream)
