@@ -795,9 +795,8 @@ static void launch_update(const lpx_revised *s, const RevisedWs &w, bool update_
     a.M = s->Binv; a.rows = s->m; a.cols = s->m; a.ld = s->ldB; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = update_xB ? s->xB : nullptr; a.xr_old = w.scal; a.col0 = 0;
     const Rank1Plan p = lpx_rank1_plan(s->m, s->m);
-    a.rows_per_block = p.rows_per_block;
     lpx_k1_begin(st);
-    hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_rank1_launch<false>(p, a, st);
     lpx_k1_end(st);
 }
 static void launch_bounded_bfs(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
@@ -1028,16 +1027,6 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_copy_row(const double *src, doubl
     if (i < n) dst[i] = src[i];
 }
 
-static int g_rank1_nt = -1;
-static bool rank1_use_nt()
-{
-    if (g_rank1_nt < 0) {
-        const char *e = getenv("LPX_RANK1_NT");
-        g_rank1_nt = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return g_rank1_nt == 1;
-}
-
 extern "C" int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
                                 double *rowr_scratch, void *stream)
 {
@@ -1051,10 +1040,8 @@ extern "C" int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t l
     Rank1Args a{};
     a.M = M; a.rows = rows; a.cols = cols; a.ld = ld; a.e = e; a.rowr = rowr_scratch; a.r = r; a.ctrl = nullptr;
     const Rank1Plan p = lpx_rank1_plan(rows, cols);
-    a.rows_per_block = p.rows_per_block;
     lpx_k1_begin(st);
-    if (rank1_use_nt()) hipLaunchKernelGGL((k_rank1<false, true>), p.grid, dim3(LPX_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_rank1<false, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_rank1_launch<false>(p, a, st);
     lpx_k1_end(st);
     LPX_LAUNCH_CHECK();
     return LPX_OK;

@@ -26,21 +26,22 @@ struct Rank1Args {
     int64_t col0;          // tableau form: global index of local column 0
 };
 
-template <bool TABLEAU, bool NT>
+template <int NT>
 __device__ __forceinline__ d2_t lpx_ld2(const double *p)
 {
-    if (NT) return __builtin_nontemporal_load((const d2_t *)p);
+    if (NT == 1 || NT == 2) return __builtin_nontemporal_load((const d2_t *)p);
     return *(const d2_t *)p;
 }
-template <bool NT>
+template <int NT>
 __device__ __forceinline__ void lpx_st2(double *p, d2_t v)
 {
-    if (NT) __builtin_nontemporal_store(v, (d2_t *)p);
+    if (NT == 1 || NT == 3) __builtin_nontemporal_store(v, (d2_t *)p);
     else *(d2_t *)p = v;
 }
 
-template <bool TABLEAU, bool NT>
-__global__ __launch_bounds__(LPX_BLOCK) void k_rank1(Rank1Args a)
+// VPT = 16-byte vectors per lane per row (a workgroup covers 512*VPT columns), UNROLL = rows in flight.
+template <bool TABLEAU, int NT, int VPT, int UNROLL>
+__global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
 {
     int64_t r = a.r;
     int64_t unit_col = -1;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_rank1(Rank1Args a)
         r = a.ctrl->leave_r;
         if (TABLEAU) unit_col = a.ctrl->enter_j - a.col0;
     }
+    const int nthr = blockDim.x;
     const int64_t row0 = (int64_t)blockIdx.y * a.rows_per_block;
     const int64_t row1 = (row0 + a.rows_per_block < a.rows) ? row0 + a.rows_per_block : a.rows;
     const double *__restrict__ e = a.e;
@@ -56,78 +58,143 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_rank1(Rank1Args a)
     if (!TABLEAU && a.xB != nullptr && blockIdx.x == 0) {
         // primal_solvers.py:251-253  bfs = E @ bfs
         const double xr = *a.xr_old;
-        for (int64_t i = row0 + threadIdx.x; i < row1; i += LPX_BLOCK) {
+        for (int64_t i = row0 + threadIdx.x; i < row1; i += nthr) {
             const double ei = e[i];
             a.xB[i] = (i == r) ? ei * xr : fma(ei, xr, a.xB[i]);
         }
     }
 
-    const int64_t col = ((int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x) * 2;
-    if (col >= a.cols) return;
-    const d2_t pr = *(const d2_t *)(a.rowr + col);
-    // tableau form: the entering column becomes the unit vector exactly (primal_solvers.py:65 keeps basic
-    // reduced costs at exactly 0; a carried tableau must do the same for the whole column)
-    const bool fix0 = TABLEAU && (col == unit_col);
-    const bool fix1 = TABLEAU && (col + 1 == unit_col);
-
-    double *p = a.M + row0 * a.ld + col;
-    const int64_t ld = a.ld;
-    int64_t i = row0;
-#define LPX_R1_ROW(vv, ii)                                                \
-    {                                                                     \
-        const double ei = e[ii];                                          \
-        if ((ii) == r) {                                                  \
-            vv[0] = ei * pr[0];                                           \
-            vv[1] = ei * pr[1];                                           \
-        } else {                                                          \
-            vv[0] = fma(ei, pr[0], vv[0]);                                \
-            vv[1] = fma(ei, pr[1], vv[1]);                                \
-        }                                                                 \
-        if (fix0) vv[0] = ((ii) == r) ? 1.0 : 0.0;                        \
-        if (fix1) vv[1] = ((ii) == r) ? 1.0 : 0.0;                        \
+    const int64_t colbase = ((int64_t)blockIdx.x * (nthr * VPT) + threadIdx.x) * 2;
+    d2_t pr[VPT];
+    bool live[VPT], fix0[VPT], fix1[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int64_t col = colbase + (int64_t)v * (2 * nthr);
+        live[v] = col < a.cols;
+        pr[v] = live[v] ? *(const d2_t *)(a.rowr + col) : d2_t{0.0, 0.0};
+        // tableau form: the entering column becomes the unit vector exactly (primal_solvers.py:65 keeps basic
+        // reduced costs at exactly 0; a carried tableau must do the same for the whole column)
+        fix0[v] = TABLEAU && (col == unit_col);
+        fix1[v] = TABLEAU && (col + 1 == unit_col);
     }
-    for (; i + 4 <= row1; i += 4) {
-        d2_t x0 = lpx_ld2<TABLEAU, NT>(p);
-        d2_t x1 = lpx_ld2<TABLEAU, NT>(p + ld);
-        d2_t x2 = lpx_ld2<TABLEAU, NT>(p + 2 * ld);
-        d2_t x3 = lpx_ld2<TABLEAU, NT>(p + 3 * ld);
-        LPX_R1_ROW(x0, i)
-        LPX_R1_ROW(x1, i + 1)
-        LPX_R1_ROW(x2, i + 2)
-        LPX_R1_ROW(x3, i + 3)
-        lpx_st2<NT>(p, x0);
-        lpx_st2<NT>(p + ld, x1);
-        lpx_st2<NT>(p + 2 * ld, x2);
-        lpx_st2<NT>(p + 3 * ld, x3);
-        p += 4 * ld;
+    if (!live[0]) return;
+
+    const int64_t ld = a.ld;
+    double *p = a.M + row0 * ld + colbase;
+    int64_t i = row0;
+    for (; i + UNROLL <= row1; i += UNROLL) {
+        d2_t x[UNROLL][VPT];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (live[v]) x[u][v] = lpx_ld2<NT>(p + u * ld + v * (2 * nthr));
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const double ei = e[i + u];
+            const bool isr = (i + u) == r;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                if (isr) {
+                    x[u][v][0] = ei * pr[v][0];
+                    x[u][v][1] = ei * pr[v][1];
+                } else {
+                    x[u][v][0] = fma(ei, pr[v][0], x[u][v][0]);
+                    x[u][v][1] = fma(ei, pr[v][1], x[u][v][1]);
+                }
+                if (fix0[v]) x[u][v][0] = isr ? 1.0 : 0.0;
+                if (fix1[v]) x[u][v][1] = isr ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (live[v]) lpx_st2<NT>(p + u * ld + v * (2 * nthr), x[u][v]);
+        p += UNROLL * ld;
     }
     for (; i < row1; ++i) {
-        d2_t x0 = lpx_ld2<TABLEAU, NT>(p);
-        LPX_R1_ROW(x0, i)
-        lpx_st2<NT>(p, x0);
+        const double ei = e[i];
+        const bool isr = i == r;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            if (!live[v]) continue;
+            d2_t x0 = lpx_ld2<NT>(p + v * (2 * nthr));
+            if (isr) {
+                x0[0] = ei * pr[v][0];
+                x0[1] = ei * pr[v][1];
+            } else {
+                x0[0] = fma(ei, pr[v][0], x0[0]);
+                x0[1] = fma(ei, pr[v][1], x0[1]);
+            }
+            if (fix0[v]) x0[0] = isr ? 1.0 : 0.0;
+            if (fix1[v]) x0[1] = isr ? 1.0 : 0.0;
+            lpx_st2<NT>(p + v * (2 * nthr), x0);
+        }
         p += ld;
     }
-#undef LPX_R1_ROW
 }
 
-// Host-side launch plan: 512 columns per workgroup; rows_per_block chosen so that the grid is many times the
-// 2048 resident workgroups (256 CUs x 8) -- a grid that only just exceeds residency has a 2x tail.
+// Host-side launch plan.  rows_per_block is chosen so that the grid is many times the ~2048 resident
+// workgroups (256 CUs x 8): a grid that only just exceeds residency has a 2x tail.
 struct Rank1Plan {
     dim3 grid;
     int64_t rows_per_block;
+    int vpt, unroll, nt, threads;
 };
+static inline int lpx_env_int(const char *name, int dflt)
+{
+    const char *env = getenv(name);
+    return (env && *env) ? atoi(env) : dflt;
+}
 static inline Rank1Plan lpx_rank1_plan(int64_t rows, int64_t cols)
 {
-    int64_t rpb = 64;
-    const char *env = getenv("LPX_RANK1_ROWS");
-    if (env && atoi(env) > 0) rpb = atoi(env);
-    const int64_t nstrips = lpx_cdiv(cols, 2 * LPX_BLOCK);
+    Rank1Plan p;
+    // defaults from the sweep on MI355X (tools/k1_sweep.py, profiles/): one row x 512 columns per workgroup,
+    // non-temporal loads and stores -- workgroups are dispatched x-fastest, so the chip-wide access front
+    // walks the matrix in address order.
+    p.vpt = lpx_env_int("LPX_RANK1_VPT", 1);
+    p.unroll = lpx_env_int("LPX_RANK1_UNROLL", 1);
+    // non-temporal only when the matrix cannot stay in the 256 MiB Infinity Cache between pivots
+    p.nt = lpx_env_int("LPX_RANK1_NT", (rows * cols * 8 > ((int64_t)192 << 20)) ? 1 : 0);
+    p.threads = lpx_env_int("LPX_RANK1_THREADS", LPX_BLOCK);
+    if (p.threads != 64 && p.threads != 128 && p.threads != 512 && p.threads != 1024) p.threads = LPX_BLOCK;
+    int64_t rpb = lpx_env_int("LPX_RANK1_ROWS", 1);
+    if (p.vpt != 2 && p.vpt != 4) p.vpt = 1;
+    if (p.unroll != 1 && p.unroll != 2 && p.unroll != 8 && p.unroll != 16) p.unroll = 4;
+    if (p.nt < 0 || p.nt > 3) p.nt = 0;
+    const int64_t nstrips = lpx_cdiv(cols, 2 * (int64_t)p.threads * p.vpt);
     // small problems: shrink the tile until there are enough workgroups to occupy the chip
     while (rpb > 4 && nstrips * lpx_cdiv(rows, rpb) < 1024) rpb /= 2;
-    Rank1Plan p;
+    if (rpb < p.unroll) p.unroll = rpb >= 8 ? 8 : rpb >= 4 ? 4 : rpb >= 2 ? 2 : 1;
     p.rows_per_block = rpb;
     p.grid = dim3((unsigned)nstrips, (unsigned)lpx_cdiv(rows, rpb), 1);
     return p;
+}
+template <bool TABLEAU>
+static inline void lpx_rank1_launch(const Rank1Plan &p, Rank1Args a, hipStream_t st)
+{
+    a.rows_per_block = p.rows_per_block;
+#define LPX_R1_GO(NT, VPT, UN) hipLaunchKernelGGL((k_rank1<TABLEAU, NT, VPT, UN>), p.grid, dim3(p.threads), 0, st, a)
+#define LPX_R1_UN(NT, VPT)                          \
+    switch (p.unroll) {                             \
+    case 16: LPX_R1_GO(NT, VPT, 16); break;         \
+    case 8: LPX_R1_GO(NT, VPT, 8); break;           \
+    case 2: LPX_R1_GO(NT, VPT, 2); break;           \
+    case 1: LPX_R1_GO(NT, VPT, 1); break;           \
+    default: LPX_R1_GO(NT, VPT, 4); break;          \
+    }
+#define LPX_R1_VPT(NT)                              \
+    if (p.vpt == 4) { LPX_R1_UN(NT, 4) } else if (p.vpt == 2) { LPX_R1_UN(NT, 2) } else { LPX_R1_UN(NT, 1) }
+    switch (p.nt) {
+    case 1: LPX_R1_VPT(1) break;
+    case 2: LPX_R1_VPT(2) break;
+    case 3: LPX_R1_VPT(3) break;
+    default: LPX_R1_VPT(0) break;
+    }
+#undef LPX_R1_VPT
+#undef LPX_R1_UN
+#undef LPX_R1_GO
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -245,26 +245,14 @@ static inline int64_t t_prep_len(const lpx_tableau *s)
     const int64_t a = lpx_roundup(s->n + 1, 2), b = s->m + 1;
     return a > b ? a : b;
 }
-static int g_t_nt = -1;
-static bool t_use_nt()
-{
-    if (g_t_nt < 0) {
-        const char *e = getenv("LPX_RANK1_NT");
-        g_t_nt = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return g_t_nt == 1;
-}
-
 static void t_launch_update(const lpx_tableau *s, const TabWs &w, hipStream_t st)
 {
     Rank1Args a{};
     a.M = s->T; a.rows = s->m + 1; a.cols = s->n + 1; a.ld = s->ld; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
     const Rank1Plan p = lpx_rank1_plan(a.rows, a.cols);
-    a.rows_per_block = p.rows_per_block;
     lpx_k1_begin(st);
-    if (t_use_nt()) hipLaunchKernelGGL((k_rank1<true, true>), p.grid, dim3(LPX_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_rank1<true, false>), p.grid, dim3(LPX_BLOCK), 0, st, a);
+    lpx_rank1_launch<true>(p, a, st);
     lpx_k1_end(st);
 }
 
