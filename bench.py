@@ -54,10 +54,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal knobs (one-GPU box): LPX_BENCH_BACKEND=gloo LPX_BENCH_ONE_DEVICE=1 put every rank on cuda:0
+    backend = os.environ.get("LPX_BENCH_BACKEND", "nccl")
+    if os.environ.get("LPX_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     if args.workload == "batch":
@@ -90,7 +97,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     import ctypes as C
@@ -140,18 +147,25 @@ def main():
     }
     if rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, m, n, A_cols, b, c, basis, solver)
+    elif rank == 0:
+        # N>1: rank 0 regenerates the whole matrix and checks the partitioned run's first pivots against the oracle
+        full = problems.gen_primal_columns(m, n, args.seed, 0, n)
+        kc = args.cpu_pivots if args.cpu_pivots is not None else (6 if m >= 10000 else 200)
+        chk = cpu_baseline(args, m, n, full[0], full[1], full[2], full[3], solver, kc=kc)
+        out["parity"] = None if chk is None else chk["parity"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, m, n, A, b, c, basis, solver):
+def cpu_baseline(args, m, n, A, b, c, basis, solver, kc=None):
     """Oracle tableau loop (C, OpenMP) on the host cores, bounded sample; also the parity gate of the timed run."""
     from oracle import oracle as O
 
     cores = min(16, os.cpu_count() or 1)
-    kc = args.cpu_pivots
+    if kc is None:
+        kc = args.cpu_pivots
     if kc is None:
         kc = 12 if m >= 10000 else 400
     if kc <= 0:
@@ -199,7 +213,7 @@ def bench_batch(args, rank, world, group):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     piv = int(solver.pivots.sum().item())

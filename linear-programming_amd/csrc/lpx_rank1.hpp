@@ -48,7 +48,12 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
     if (a.ctrl) {
         if (a.ctrl->status != LPX_RUNNING || a.ctrl->flip) return;
         r = a.ctrl->leave_r;
-        if (TABLEAU) unit_col = a.ctrl->enter_j - a.col0;
+        if (TABLEAU) {
+            // local index of the entering column; another rank's column (column partition) must not alias the
+            // x_B column at local index cols-1
+            unit_col = a.ctrl->enter_j - a.col0;
+            if (unit_col < 0 || unit_col >= a.cols - 1) unit_col = -1;
+        }
     }
     const int nthr = blockDim.x;
     const int64_t row0 = (int64_t)blockIdx.y * a.rows_per_block;

@@ -19,6 +19,41 @@ from .exceptions import BasisIsPrimalInfeasibleError, PrimalIsUnboundedError
 from .preprocessing import ProblemPreprocessingUtils
 
 
+def column_range(n, rank, world):
+    """Global columns [j0, j1) owned by `rank` in an N-way column partition."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+class ProposalExchange:
+    """The one collective of a column-partitioned pivot: all-gather of the ranks' proposals.
+
+    A proposal is ``msg_len`` float64: [local min rc, global index of the first owned negative column (2^62 if
+    none), that column of T (m values), its reduced cost].  Backend "nccl" (= RCCL over xGMI) gathers device
+    buffers in stream order; backend "gloo" (CPU rehearsal, tests) stages through the host.
+    """
+
+    def __init__(self, group, msg_len, device):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.nranks = dist.get_world_size(group)
+        self.msg = int(msg_len)
+        self.sendbuf = torch.zeros(self.msg, dtype=torch.float64, device=device)
+        self.recvbuf = torch.zeros(self.msg * self.nranks, dtype=torch.float64, device=device)
+        self.staged = dist.get_backend(group) == "gloo" and self.sendbuf.is_cuda
+
+    def all_gather(self):
+        if self.staged:
+            send = self.sendbuf.cpu()
+            recv = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.recvbuf.copy_(recv)
+        else:
+            self.dist.all_gather_into_tensor(self.recvbuf, self.sendbuf, group=self.group)
+        return self.recvbuf
+
+
 class TableauEngine:
     """Device state of one (slice of a) tableau."""
 
@@ -57,14 +92,8 @@ class TableauEngine:
         self.group = group
         self.nranks = 1
         if group is not None:
-            import torch.distributed as dist
-
-            self.dist = dist
-            self.nranks = dist.get_world_size(group)
-            self.msg = int(self.lib.lpx_tableau_msg_len(self.m))
-            self.sendbuf = torch.zeros(self.msg, dtype=torch.float64, device="cuda")
-            self.recvbuf = torch.zeros(self.msg * self.nranks, dtype=torch.float64, device="cuda")
-            self._cpu_staging = dist.get_backend(group) == "gloo"
+            self.exchange = ProposalExchange(group, self.lib.lpx_tableau_msg_len(self.m), "cuda")
+            self.nranks = self.exchange.nranks
 
     # ------------------------------------------------------------------ construction from a host problem
     @classmethod
@@ -113,19 +142,11 @@ class TableauEngine:
         if self.group is None:
             _lib.check(self.lib.lpx_tableau_iterate(C.byref(self.s), int(iters), st))
             return
+        ex = self.exchange
         for _ in range(int(iters)):
-            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), self.sendbuf.data_ptr(), st))
-            self._all_gather()
-            _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), self.recvbuf.data_ptr(), self.nranks, st))
-
-    def _all_gather(self):
-        if self._cpu_staging:  # gloo rehearsal (CPU tests / 2 ranks on one GPU): stage through the host
-            send = self.sendbuf.cpu()
-            recv = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
-            self.dist.all_gather_into_tensor(recv, send, group=self.group)
-            self.recvbuf.copy_(recv)
-        else:  # RCCL over xGMI, stream-ordered with the kernels
-            self.dist.all_gather_into_tensor(self.recvbuf, self.sendbuf, group=self.group)
+            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))
+            ex.all_gather()
+            _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
 
     def run(self, maxiters):
         st = stream_ptr()
@@ -170,8 +191,7 @@ class PrimalTableauSimplexSolver:
             if group is not None:
                 import torch.distributed as dist
 
-                rank, size = dist.get_rank(group), dist.get_world_size(group)
-                j0, j1 = self.n * rank // size, self.n * (rank + 1) // size
+                j0, j1 = column_range(self.n, dist.get_rank(group), dist.get_world_size(group))
             A_cols = A32[:, j0:j1]
         else:  # caller supplies only its slice (already float32, b >= 0): large problems
             j0, j1 = columns

@@ -1,0 +1,106 @@
+"""Worker of the column-partition tests (one process per rank, launched by torch.distributed.run).
+
+mode "cpu": the host protocol (ProposalExchange + column_range) driven by a NumPy stand-in of the device kernels,
+            gloo on CPU tensors -- checks message layout, winner selection and the replicated ratio test.
+mode "gpu": the product path (PrimalTableauSimplexSolver with a process group) with every rank on cuda:0 and the
+            gloo backend staging the all-gather through the host (2-rank rehearsal on the one-GPU box).
+Both compare against the single-process oracle on the same problem.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import linprog_amd  # noqa: E402,F401
+from linprog_amd import problems  # noqa: E402
+from linprog_amd.tableau import ProposalExchange, column_range  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+NOIDX = float(2 ** 62)
+
+
+def numpy_rank(c, A, b, basis, rank, world, ex, maxiters):
+    """Column-partitioned tableau simplex with NumPy standing in for lpx_tableau_propose/commit."""
+    c32, A32, b32 = O.preprocess(c, A, b)
+    m, n = A32.shape
+    j0, j1 = column_range(n, rank, world)
+    nl = j1 - j0
+    T = np.zeros((m + 1, nl + 1))
+    T[:m, :nl] = A32[:, j0:j1]
+    T[:m, nl] = b32
+    T[m, :nl] = c32[j0:j1]
+    basis = np.array(basis, dtype=np.int64)
+    log = []
+    f32 = True
+    for it in range(maxiters):
+        rc = T[m, :nl]
+        neg = np.flatnonzero(rc < 0)
+        send = np.zeros(ex.msg)
+        send[0] = rc.min() if nl else np.inf
+        send[1] = j0 + neg[0] if neg.size else NOIDX
+        if neg.size:
+            send[2:2 + m + 1] = T[:, neg[0]]
+        ex.sendbuf.copy_(torch.from_numpy(send))
+        recv = ex.all_gather().numpy().reshape(world, ex.msg)
+        mn = recv[:, 0].min()
+        if mn >= 0 or abs(mn) <= 1e-8:
+            return log, basis, T[:m, nl].copy(), True
+        win = int(np.argmin(recv[:, 1]))
+        j = int(recv[win, 1])
+        d = recv[win, 2:2 + m + 1]
+        r, theta, dmax = O.ratio_primal(T[:m, nl].copy(), d[:m].copy(), f32)
+        e = (-d) / d[r]
+        e[r] = 1.0 / d[r]
+        log.append([r, j, int(basis[r])])
+        basis[r] = j
+        T = O.rank1_update(np.ascontiguousarray(T), r, e)
+        if j0 <= j < j1:
+            T[:, j - j0] = 0.0
+            T[r, j - j0] = 1.0
+        f32 = False
+    return log, basis, T[:m, nl].copy(), False
+
+
+def main():
+    mode = sys.argv[1]
+    m, n, seed, maxiters = (int(v) for v in sys.argv[2:6])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    c, A, b, basis = problems.gen_primal(m, n, seed)
+    want = O.OracleRevised(c, A, b, basis, log_cap=maxiters + 1).solve(maxiters)
+    if mode == "cpu":
+        ex = ProposalExchange(dist.group.WORLD, m + 3 + ((m + 3) % 2), "cpu")
+        log, bas, xB, opt = numpy_rank(c, A, b, basis, rank, world, ex, maxiters)
+        assert log == want.log.tolist(), f"rank {rank}: pivot sequence differs"
+        assert bas.tolist() == want.basis.tolist() and opt == (want.status == O.OPTIMAL)
+    else:
+        from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+        torch.cuda.set_device(0)
+        cls = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": maxiters + 1})
+        s = cls(c, A, b, basis, group=dist.group.WORLD)
+        res = s.solve(maxiters)
+        assert s.pivot_log().tolist() == want.log.tolist(), f"rank {rank}: pivot sequence differs"
+        assert res.basis.tolist() == want.basis.tolist() and res.optimum == (want.status == O.OPTIMAL)
+        assert np.allclose(res.x, want.x, rtol=1e-9, atol=1e-9) and abs(res.cost - want.cost) <= 1e-9 * max(1, abs(want.cost))
+        # slice-construction path used by bench.py (columns=...)
+        Ab, bb, cb, basb = problems.gen_primal_columns(m, n, seed, *column_range(n, rank, world))
+        s2 = cls(cb, Ab, bb, basb, group=dist.group.WORLD, columns=column_range(n, rank, world), n_global=n)
+        r2 = s2.solve(maxiters)
+        full = problems.gen_primal_columns(m, n, seed, 0, n)
+        w2 = O.OracleTableau(full[2], full[0], full[1], full[3], log_cap=maxiters + 1).solve(maxiters)
+        assert s2.pivot_log().tolist() == w2.log.tolist()
+        assert np.allclose(r2.x, w2.x, rtol=1e-9, atol=1e-9)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok")
+
+
+if __name__ == "__main__":
+    main()

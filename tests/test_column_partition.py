@@ -1,0 +1,38 @@
+"""N>1 path of the column-partitioned tableau: world_size-2/3 gloo runs (CPU protocol test, GPU rehearsal)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests._util import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, nproc, m, n, seed, maxiters):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_colpart_worker.py"), mode, str(m), str(n), str(seed), str(maxiters)]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count(" ok") == nproc
+
+
+@pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
+def test_protocol_cpu_gloo(nproc, m, n):
+    _run("cpu", nproc, m, n, 1, 100000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
+def test_product_path_two_ranks_one_gpu(nproc, m, n):
+    _run("gpu", nproc, m, n, 2, 100000)
