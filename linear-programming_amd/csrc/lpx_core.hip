@@ -13,6 +13,7 @@
 
 #include "lpx_device.hpp"
 #include "lpx_rank1.hpp"
+#include "lpx_graph.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
 // error string (thread local)
@@ -35,6 +36,11 @@ LpxK1Profile &lpx_k1_profile()
 {
     static LpxK1Profile p;
     return p;
+}
+LpxGraphCache &lpx_graph_cache()
+{
+    static LpxGraphCache c;
+    return c;
 }
 extern "C" int lpx_profile_k1(int enable)
 {
@@ -352,26 +358,26 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
 __device__ __forceinline__ VI combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
 {
     VI b{LPX_INF, LPX_NOIDX};
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK)
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
         if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
     return block_argmin(b, red);
 }
 __device__ __forceinline__ double combine_min(const double *v, int64_t np, BlockRed &red)
 {
     double b = LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmin(b, v[k]);
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmin(b, v[k]);
     return block_min(b, red);
 }
 __device__ __forceinline__ double combine_max(const double *v, int64_t np, BlockRed &red)
 {
     double b = -LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmax(b, v[k]);
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmax(b, v[k]);
     return block_max(b, red);
 }
 __device__ __forceinline__ int64_t combine_imin(const int64_t *i, int64_t np, BlockRed &red)
 {
     int64_t b = LPX_NOIDX;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = i[k] < b ? i[k] : b;
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = i[k] < b ? i[k] : b;
     return block_imin(b, red);
 }
 
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_direction(DirArgs a)
     } else if (a.kind == DIR_BOUNDED) {
         // first argmax over the partials: value descending, index ascending
         VI b{LPX_INF, LPX_NOIDX};
-        for (int64_t k = threadIdx.x; k < a.nprice; k += LPX_BLOCK)
+        for (int64_t k = threadIdx.x; k < a.nprice; k += blockDim.x)
             if (vi_less(-a.price.v0[k], a.price.i0[k], b.v, b.i)) { b.v = -a.price.v0[k]; b.i = a.price.i0[k]; }
         b = block_argmin(b, red);
         const double mx = -b.v;
@@ -814,34 +820,45 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
     LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "bad kind");
     LPX_REQUIRE(kind != LPX_KIND_BOUNDED || (s->lb && s->ub), "bounded solver needs lb/ub");
     const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
-    hipStream_t st = (hipStream_t)stream;
-    for (int64_t it = 0; it < iters; ++it) {
+    hipStream_t st0 = (hipStream_t)stream;
+    const lpx_revised sv = *s;
+    const lpx_revised *sp = &sv;
+    auto one = [&](hipStream_t st) {
         if (kind == LPX_KIND_PRIMAL) {
-            launch_pricing_sums(s, w, st);
-            launch_fin(s, w, FIN_PRIMAL, nullptr, st);
-            launch_direction(s, w, DIR_PRIMAL, -1, st);
-            launch_prepare(s, w, PREP_PRIMAL, -1, st);
-            launch_update(s, w, true, st);
+            launch_pricing_sums(sp, w, st);
+            launch_fin(sp, w, FIN_PRIMAL, nullptr, st);
+            launch_direction(sp, w, DIR_PRIMAL, -1, st);
+            launch_prepare(sp, w, PREP_PRIMAL, -1, st);
+            launch_update(sp, w, true, st);
         } else if (kind == LPX_KIND_DUAL) {
-            hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)s->xB, s->m, s->ctrl);
-            launch_colsum_A(s, w, W_BINV_ROW, w.zpart2, st);
-            launch_pricing_sums(s, w, st);
-            launch_fin(s, w, FIN_DUAL, nullptr, st);
-            launch_direction(s, w, DIR_DUAL, -1, st);
-            launch_prepare(s, w, PREP_DUAL, -1, st);
-            launch_update(s, w, true, st);
+            hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)sp->xB, sp->m, sp->ctrl);
+            launch_colsum_A(sp, w, W_BINV_ROW, w.zpart2, st);
+            launch_pricing_sums(sp, w, st);
+            launch_fin(sp, w, FIN_DUAL, nullptr, st);
+            launch_direction(sp, w, DIR_DUAL, -1, st);
+            launch_prepare(sp, w, PREP_DUAL, -1, st);
+            launch_update(sp, w, true, st);
         } else {
-            hipLaunchKernelGGL(k_clear_flip, dim3(1), dim3(1), 0, st, s->ctrl);
-            launch_pricing_sums(s, w, st);
-            launch_fin(s, w, FIN_BOUNDED, nullptr, st);
-            launch_direction(s, w, DIR_BOUNDED, -1, st);
-            launch_prepare(s, w, PREP_BOUNDED, -1, st);
-            launch_update(s, w, false, st);
-            launch_bounded_bfs(s, w, st);
+            hipLaunchKernelGGL(k_clear_flip, dim3(1), dim3(1), 0, st, sp->ctrl);
+            launch_pricing_sums(sp, w, st);
+            launch_fin(sp, w, FIN_BOUNDED, nullptr, st);
+            launch_direction(sp, w, DIR_BOUNDED, -1, st);
+            launch_prepare(sp, w, PREP_BOUNDED, -1, st);
+            launch_update(sp, w, false, st);
+            launch_bounded_bfs(sp, w, st);
         }
-    }
-    LPX_LAUNCH_CHECK();
-    return LPX_OK;
+    };
+    struct {
+        lpx_revised s;
+        int kind, vpt, unroll, nt, threads;
+        int64_t rpb;
+    } key;
+    memset(&key, 0, sizeof key);
+    const Rank1Plan plan = lpx_rank1_plan(s->m, s->m);
+    key.s = sv; key.kind = kind; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt;
+    key.threads = plan.threads; key.rpb = plan.rows_per_block;
+    if (iters <= 0) return LPX_OK;
+    return lpx_run_iterations(&key, sizeof key, iters, st0, one);
 }
 
 extern "C" int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream)
@@ -1124,7 +1141,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_red_stage2(RedArgs a, int64_t np)
         if (threadIdx.x == 0) { a.out_val[0] = mn; a.out_idx[0] = (j == LPX_NOIDX) ? -1 : j; }
     } else if (a.op == RED_ARGMAX) {
         VI b{LPX_INF, LPX_NOIDX};
-        for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK)
+        for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
             if (vi_less(-a.P.v0[k], a.P.i0[k], b.v, b.i)) { b.v = -a.P.v0[k]; b.i = a.P.i0[k]; }
         b = block_argmin(b, red);
         if (threadIdx.x == 0) { a.out_val[0] = -b.v; a.out_idx[0] = b.i; }

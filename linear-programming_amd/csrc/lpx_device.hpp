@@ -13,6 +13,7 @@
 
 #define LPX_BLOCK 256
 #define LPX_WAVES (LPX_BLOCK / 64)
+#define LPX_MAXWAVES 16 /* reductions work for any workgroup size up to 1024 */
 #define LPX_MAXP 2048 /* capacity of one partial array */
 #define LPX_ATOL 1e-8 /* numpy.isclose(x, 0) default atol, primal_solvers.py:142 */
 #define LPX_RTOL 1e-5
@@ -102,8 +103,8 @@ __device__ __forceinline__ T wave_sum(T v)
 
 // LDS scratch for block-level reductions (one per kernel)
 struct BlockRed {
-    double v[LPX_WAVES * 2];
-    int64_t i[LPX_WAVES * 2];
+    double v[LPX_MAXWAVES];
+    int64_t i[LPX_MAXWAVES];
 };
 
 // all threads of the block receive the result; red must not be in use
@@ -114,8 +115,8 @@ __device__ __forceinline__ VI block_argmin(VI a, BlockRed &red)
     if ((threadIdx.x & 63) == 0) { red.v[w] = a.v; red.i[w] = a.i; }
     __syncthreads();
     VI r{red.v[0], red.i[0]};
-#pragma unroll
-    for (int k = 1; k < LPX_WAVES; ++k)
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 1; k < nw; ++k)
         if (vi_less(red.v[k], red.i[k], r.v, r.i)) { r.v = red.v[k]; r.i = red.i[k]; }
     __syncthreads();
     return r;
@@ -127,8 +128,8 @@ __device__ __forceinline__ double block_min(double v, BlockRed &red)
     if ((threadIdx.x & 63) == 0) red.v[w] = v;
     __syncthreads();
     double r = red.v[0];
-#pragma unroll
-    for (int k = 1; k < LPX_WAVES; ++k) r = fmin(r, red.v[k]);
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 1; k < nw; ++k) r = fmin(r, red.v[k]);
     __syncthreads();
     return r;
 }
@@ -139,8 +140,8 @@ __device__ __forceinline__ double block_max(double v, BlockRed &red)
     if ((threadIdx.x & 63) == 0) red.v[w] = v;
     __syncthreads();
     double r = red.v[0];
-#pragma unroll
-    for (int k = 1; k < LPX_WAVES; ++k) r = fmax(r, red.v[k]);
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 1; k < nw; ++k) r = fmax(r, red.v[k]);
     __syncthreads();
     return r;
 }
@@ -151,8 +152,8 @@ __device__ __forceinline__ int64_t block_imin(int64_t v, BlockRed &red)
     if ((threadIdx.x & 63) == 0) red.i[w] = v;
     __syncthreads();
     int64_t r = red.i[0];
-#pragma unroll
-    for (int k = 1; k < LPX_WAVES; ++k) r = red.i[k] < r ? red.i[k] : r;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 1; k < nw; ++k) r = red.i[k] < r ? red.i[k] : r;
     __syncthreads();
     return r;
 }

@@ -24,6 +24,10 @@ struct Rank1Args {
     double *xB;            // revised form: x_B updated by the first column strip (else nullptr)
     const double *xr_old;  // revised form: old x_B[r]
     int64_t col0;          // tableau form: global index of local column 0
+    // tableau form: pricing fused into the update -- the workgroups that produce the new reduced-cost row
+    // (last row of M) also reduce it: price_v0[strip] = min rc, price_i0[strip] = first global column with rc<0
+    double *price_v0;
+    int64_t *price_i0;
 };
 
 template <int NT>
@@ -82,11 +86,14 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
         fix0[v] = TABLEAU && (col == unit_col);
         fix1[v] = TABLEAU && (col + 1 == unit_col);
     }
-    if (!live[0]) return;
-
     const int64_t ld = a.ld;
+    const int64_t lastrow = a.rows - 1;
+    d2_t lastv[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) lastv[v] = d2_t{0.0, 0.0};
     double *p = a.M + row0 * ld + colbase;
     int64_t i = row0;
+    if (live[0]) {
     for (; i + UNROLL <= row1; i += UNROLL) {
         d2_t x[UNROLL][VPT];
 #pragma unroll
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
                 }
                 if (fix0[v]) x[u][v][0] = isr ? 1.0 : 0.0;
                 if (fix1[v]) x[u][v][1] = isr ? 1.0 : 0.0;
+                if (TABLEAU && (i + u) == lastrow) lastv[v] = x[u][v];
             }
         }
 #pragma unroll
@@ -134,9 +142,36 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
             }
             if (fix0[v]) x0[0] = isr ? 1.0 : 0.0;
             if (fix1[v]) x0[1] = isr ? 1.0 : 0.0;
+            if (TABLEAU && i == lastrow) lastv[v] = x0;
             lpx_st2<NT>(p + v * (2 * nthr), x0);
         }
         p += ld;
+    }
+    } // live[0]
+
+    if (TABLEAU && a.price_v0 != nullptr && row1 == a.rows) { // workgroup-uniform
+        __shared__ BlockRed red;
+        double mn = LPX_INF;
+        int64_t jn = LPX_NOIDX;
+        const int64_t nstruct = a.cols - 1; // column cols-1 is x_B / -objective
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int64_t col = colbase + (int64_t)v * (2 * nthr);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (col + q < nstruct) {
+                    const double rc = lastv[v][q];
+                    mn = fmin(mn, rc);
+                    if (rc < 0.0 && a.col0 + col + q < jn) jn = a.col0 + col + q;
+                }
+            }
+        }
+        mn = block_min(mn, red);
+        jn = block_imin(jn, red);
+        if (threadIdx.x == 0) {
+            a.price_v0[blockIdx.x] = mn;
+            a.price_i0[blockIdx.x] = jn;
+        }
     }
 }
 

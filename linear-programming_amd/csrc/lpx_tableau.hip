@@ -12,6 +12,7 @@
 // to pick the global entering column, run the ratio test redundantly on its x_B replica and update its slice.
 #include "lpx_device.hpp"
 #include "lpx_rank1.hpp"
+#include "lpx_graph.hpp"
 
 struct TabWs {
     double *d, *e, *rowr, *scal;
@@ -65,16 +66,23 @@ static int check_tableau(const lpx_tableau *s)
     return LPX_OK;
 }
 
-// K3 (tableau): scan the carried reduced-cost row: per-workgroup (min rc, first global column with rc<0)
-__global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P)
+// K3 (tableau): scan the carried reduced-cost row: one partial (min rc, first global column with rc<0) per
+// column strip of K1's launch plan, i.e. in the same layout K1's fused pricing epilogue writes afterwards.
+__global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P, int64_t strip)
 {
     __shared__ BlockRed red;
     if (s.ctrl->status != LPX_RUNNING) return;
-    const int64_t j = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    const bool in = j < s.n;
-    const double rc = in ? s.T[s.m * s.ld + j] : LPX_INF;
-    const double mn = block_min(rc, red);
-    const int64_t jn = block_imin((in && rc < 0.0) ? s.col0 + j : LPX_NOIDX, red);
+    const int64_t c0 = (int64_t)blockIdx.x * strip;
+    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    double mn = LPX_INF;
+    int64_t jn = LPX_NOIDX;
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
+        const double rc = s.T[s.m * s.ld + j];
+        mn = fmin(mn, rc);
+        if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+    }
+    mn = block_min(mn, red);
+    jn = block_imin(jn, red);
     if (threadIdx.x == 0) {
         P.v0[blockIdx.x] = mn;
         P.i0[blockIdx.x] = jn;
@@ -84,26 +92,26 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P
 __device__ __forceinline__ VI t_combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
 {
     VI b{LPX_INF, LPX_NOIDX};
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK)
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
         if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
     return block_argmin(b, red);
 }
 __device__ __forceinline__ double t_combine_min(const double *v, int64_t np, BlockRed &red)
 {
     double b = LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmin(b, v[k]);
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmin(b, v[k]);
     return block_min(b, red);
 }
 __device__ __forceinline__ double t_combine_max(const double *v, int64_t np, BlockRed &red)
 {
     double b = -LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = fmax(b, v[k]);
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmax(b, v[k]);
     return block_max(b, red);
 }
 __device__ __forceinline__ int64_t t_combine_imin(const int64_t *i, int64_t np, BlockRed &red)
 {
     int64_t b = LPX_NOIDX;
-    for (int64_t k = threadIdx.x; k < np; k += LPX_BLOCK) b = i[k] < b ? i[k] : b;
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = i[k] < b ? i[k] : b;
     return block_imin(b, red);
 }
 
@@ -240,21 +248,180 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_prepare(lpx_tableau s, Partials
     }
 }
 
+// Small tableaus: entering decision, column gather, ratio test, eta column, pivot-row copy and bookkeeping in ONE
+// single-workgroup kernel (replaces k_t_column + k_t_prepare, or k_t_select + k_t_prepare when partitioned).
+// It is latency-bound, so it is organised as three dependent global-memory round trips (x_B + pricing partials;
+// the entering column; the pivot row) with everything else in registers / LDS: each lane keeps its <= 4 rows'
+// x_B and d values in registers, and the two block reductions each cost one barrier pair.
+#define T_SMALL_RPT 4
+#define T_SMALL_THREADS 1024
+struct SmallRed {
+    double a[LPX_MAXWAVES], b[LPX_MAXWAVES], c[LPX_MAXWAVES];
+    int64_t i[LPX_MAXWAVES];
+};
+template <bool PART>
+__global__ __launch_bounds__(T_SMALL_THREADS) void k_t_pre_small(lpx_tableau s, Partials P, int64_t nprice,
+                                                                const double *recv, int64_t nranks, int64_t msg,
+                                                                double *d_out, double *e, double *rowr)
+{
+    __shared__ SmallRed red;
+    lpx_ctrl *ctrl = s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const bool f32 = ctrl->f32_phase != 0;
+    const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    const bool lead = tid == 0;
+    const int64_t m = s.m;
+
+    // ---- round trip 1: x_B column (independent of the entering decision) + pricing partials / proposals
+    double xb[T_SMALL_RPT];
+#pragma unroll
+    for (int q = 0; q < T_SMALL_RPT; ++q) {
+        const int64_t i = tid + (int64_t)q * nthr;
+        xb[q] = (i < m) ? s.T[i * s.ld + s.n] : 0.0;
+    }
+    double mn = LPX_INF;
+    int64_t j = LPX_NOIDX, win = 0;
+    if (!PART) {
+        for (int64_t k = tid; k < nprice; k += nthr) {
+            mn = fmin(mn, P.v0[k]);
+            j = P.i0[k] < j ? P.i0[k] : j;
+        }
+        mn = wave_min(mn);
+        j = wave_imin(j);
+        if (lane == 0) { red.a[wave] = mn; red.i[wave] = j; }
+        __syncthreads();
+        mn = red.a[0];
+        j = red.i[0];
+        for (int k = 1; k < nw; ++k) {
+            mn = fmin(mn, red.a[k]);
+            j = red.i[k] < j ? red.i[k] : j;
+        }
+        __syncthreads();
+    } else {
+        for (int64_t g = 0; g < nranks; ++g) {
+            const double v = recv[g * msg];
+            const int64_t idx = (int64_t)recv[g * msg + 1];
+            mn = fmin(mn, v);
+            if (idx < j) { j = idx; win = g; }
+        }
+    }
+    const bool opt = lpx_is_optimal_min(mn);
+    if (lead) {
+        ctrl->counter += 1;
+        ctrl->price_val = mn;
+        if (opt) ctrl->status = LPX_OPTIMAL;
+        else ctrl->enter_j = j;
+    }
+    if (opt) return;
+
+    // ---- round trip 2: the entering column (d[m] = its reduced cost)
+    const double *src = PART ? recv + win * msg + 2 : s.T + (j - s.col0);
+    const int64_t stride = PART ? 1 : s.ld;
+    double dv[T_SMALL_RPT];
+    VI best{LPX_INF, LPX_NOIDX};
+    double dbest = 0.0, dmax = -LPX_INF;
+#pragma unroll
+    for (int q = 0; q < T_SMALL_RPT; ++q) {
+        const int64_t i = tid + (int64_t)q * nthr;
+        dv[q] = (i <= m) ? src[i * stride] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < T_SMALL_RPT; ++q) {
+        const int64_t i = tid + (int64_t)q * nthr;
+        if (i < m) {
+            const double th = lpx_psd(xb[q], dv[q], f32);
+            if (vi_less(th, i, best.v, best.i)) { best.v = th; best.i = i; dbest = dv[q]; }
+            dmax = fmax(dmax, dv[q]);
+        }
+        if (i <= m) d_out[i] = dv[q];
+    }
+    // argmin (theta, row) carrying d_row, and max(d): one barrier pair
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best.v, off), od = __shfl_xor(dbest, off);
+        const int64_t oi = __shfl_xor(best.i, off);
+        if (vi_less(ov, oi, best.v, best.i)) { best.v = ov; best.i = oi; dbest = od; }
+    }
+    dmax = wave_max(dmax);
+    if (lane == 0) { red.a[wave] = best.v; red.i[wave] = best.i; red.b[wave] = dbest; red.c[wave] = dmax; }
+    __syncthreads();
+    best.v = red.a[0]; best.i = red.i[0]; dbest = red.b[0]; dmax = red.c[0];
+    for (int k = 1; k < nw; ++k) {
+        if (vi_less(red.a[k], red.i[k], best.v, best.i)) { best.v = red.a[k]; best.i = red.i[k]; dbest = red.b[k]; }
+        dmax = fmax(dmax, red.c[k]);
+    }
+    if (dmax <= 0.0) { // primal_solvers.py:144-147
+        if (lead) {
+            ctrl->aux_val = dmax;
+            ctrl->status = LPX_PRIMAL_UNBOUNDED;
+        }
+        return;
+    }
+    const int64_t r = best.i;
+    const double dr = dbest;
+
+    // ---- round trip 3: old pivot row copy (+ basis[r] for the bookkeeping); eta column from registers
+    const int64_t ncopy = lpx_roundup_dev(s.n + 1, 2);
+    for (int64_t k = tid; k < ncopy; k += nthr) rowr[k] = s.T[r * s.ld + k];
+#pragma unroll
+    for (int q = 0; q < T_SMALL_RPT; ++q) {
+        const int64_t i = tid + (int64_t)q * nthr;
+        if (i <= m) e[i] = (i == r) ? 1.0 / dr : (-dv[q]) / dr; // primal_solvers.py:236-244; e[m] eliminates rc_j
+    }
+    if (lead) {
+        const int64_t leaving = s.basis[r];
+        s.basis[r] = j;
+        const int64_t ll = leaving - s.col0, jl = j - s.col0;
+        if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
+        if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+        if (s.log && ctrl->pivots < s.log_cap) {
+            s.log[3 * ctrl->pivots + 0] = r;
+            s.log[3 * ctrl->pivots + 1] = j;
+            s.log[3 * ctrl->pivots + 2] = leaving;
+        }
+        ctrl->pivots += 1;
+        ctrl->leave_r = r;
+        ctrl->leave_var = leaving;
+        ctrl->ratio_val = best.v;
+        ctrl->aux_val = dmax;
+        ctrl->flip = 0;
+        ctrl->f32_phase = 0;
+    }
+}
+static inline bool t_is_small(const lpx_tableau *s)
+{
+    if (lpx_env_int("LPX_TABLEAU_SMALL", 1) == 0) return false;
+    // measured on MI355X: one workgroup gathers a strided column slower than many once m is beyond a few hundred
+    // rows (m=1000: 11.4 us vs 3+3 us), so the single-workgroup form is kept for genuinely small tableaus
+    return s->m + 1 <= 512 && s->n + 2 <= 4096;
+}
+
 static inline int64_t t_prep_len(const lpx_tableau *s)
 {
     const int64_t a = lpx_roundup(s->n + 1, 2), b = s->m + 1;
     return a > b ? a : b;
 }
-static void t_launch_update(const lpx_tableau *s, const TabWs &w, hipStream_t st)
+static void t_launch_update(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st)
 {
     Rank1Args a{};
     a.M = s->T; a.rows = s->m + 1; a.cols = s->n + 1; a.ld = s->ld; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
-    const Rank1Plan p = lpx_rank1_plan(a.rows, a.cols);
+    a.price_v0 = w.price.v0; a.price_i0 = w.price.i0;
     lpx_k1_begin(st);
     lpx_rank1_launch<true>(p, a, st);
     lpx_k1_end(st);
 }
+static void t_launch_price(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st)
+{
+    const int64_t strip = 2 * (int64_t)p.threads * p.vpt;
+    hipLaunchKernelGGL(k_t_price, dim3(p.grid.x), dim3(LPX_BLOCK), 0, st, *s, w.price, strip);
+}
+struct TabKey {
+    lpx_tableau s;
+    int vpt, unroll, nt, threads;
+    int64_t rpb;
+    int what;
+};
 
 extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
@@ -263,16 +430,30 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     LPX_REQUIRE(s->col0 == 0 && s->n_global == s->n, "lpx_tableau_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nprice = lpx_cdiv(s->n, LPX_BLOCK), nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
-    for (int64_t it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(k_t_price, dim3((unsigned)nprice), dim3(LPX_BLOCK), 0, st, *s, w.price);
-        hipLaunchKernelGGL(k_t_column, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.price, nprice, w.ratio, w.d);
-        hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.ratio,
-                           nrow, (const double *)w.d, w.e, w.rowr);
-        t_launch_update(s, w, st);
-    }
-    LPX_LAUNCH_CHECK();
-    return LPX_OK;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    const int64_t nprice = plan.grid.x, nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
+    if (iters <= 0) return LPX_OK;
+    // K1 refreshes the pricing partials of the NEXT iteration; the first iteration of a call scans the row itself
+    t_launch_price(s, w, plan, st);
+    const lpx_tableau sv = *s;
+    const bool small = t_is_small(s);
+    auto one = [&](hipStream_t q) {
+        if (small) {
+            hipLaunchKernelGGL((k_t_pre_small<false>), dim3(1), dim3(T_SMALL_THREADS), 0, q, sv, w.price, nprice,
+                               (const double *)nullptr, (int64_t)0, (int64_t)0, w.d, w.e, w.rowr);
+        } else {
+            hipLaunchKernelGGL(k_t_column, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, q, sv, w.price, nprice, w.ratio, w.d);
+            hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(&sv), LPX_BLOCK)), dim3(LPX_BLOCK), 0, q, sv,
+                               w.ratio, nrow, (const double *)w.d, w.e, w.rowr);
+        }
+        t_launch_update(&sv, w, plan, q);
+    };
+    TabKey key;
+    memset(&key, 0, sizeof key);
+    key.s = sv; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt; key.threads = plan.threads;
+    key.rpb = plan.rows_per_block; key.what = 1;
+    return lpx_run_iterations(&key, sizeof key, iters, st, one);
 }
 
 extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *stream)
@@ -282,9 +463,11 @@ extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *
     LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nprice = lpx_cdiv(s->n, LPX_BLOCK), nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
-    hipLaunchKernelGGL(k_t_price, dim3((unsigned)nprice), dim3(LPX_BLOCK), 0, st, *s, w.price);
-    hipLaunchKernelGGL(k_t_propose, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.price, nprice, sendbuf);
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    const int64_t nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
+    t_launch_price(s, w, plan, st);
+    hipLaunchKernelGGL(k_t_propose, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.price, (int64_t)plan.grid.x, sendbuf);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }
@@ -296,12 +479,17 @@ extern "C" int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, i
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
-    hipLaunchKernelGGL(k_t_select, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks,
-                       lpx_tableau_msg_len(s->m), w.ratio, w.d);
-    hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.ratio,
-                       nrow, (const double *)w.d, w.e, w.rowr);
-    t_launch_update(s, w, st);
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    const int64_t nrow = lpx_cdiv(s->m + 1, LPX_BLOCK), msg = lpx_tableau_msg_len(s->m);
+    if (t_is_small(s)) {
+        hipLaunchKernelGGL((k_t_pre_small<true>), dim3(1), dim3(T_SMALL_THREADS), 0, st, *s, w.price, (int64_t)0, recvbuf, nranks, msg,
+                           w.d, w.e, w.rowr);
+    } else {
+        hipLaunchKernelGGL(k_t_select, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks, msg, w.ratio, w.d);
+        hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.ratio,
+                           nrow, (const double *)w.d, w.e, w.rowr);
+    }
+    t_launch_update(s, w, plan, st);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

@@ -18,6 +18,7 @@ class RevisedEngine:
 
     #: iterations enqueued between two reads of the control block
     CHUNK = 64
+    FIRST_CHUNK = 16
 
     def __init__(self, c32, A32, b32, basis, inv0, bfs0, var_state=None, lb=None, ub=None, log_cap=0):
         torch = torch_cuda()
@@ -74,8 +75,12 @@ class RevisedEngine:
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         left = int(maxiters)
         ctrl = None
+        first = True
         while left > 0:
-            k = min(left, self.CHUNK)
+            # short first chunk (eager launches): small solves end here; later chunks are long enough for
+            # liblpx to replay them as hipGraphs
+            k = min(left, self.FIRST_CHUNK if first else self.CHUNK)
+            first = False
             _lib.check(self.lib.lpx_revised_iterate(C.byref(self.s), kind, k, st))
             left -= k
             ctrl = self.read_ctrl()

@@ -58,6 +58,7 @@ class TableauEngine:
     """Device state of one (slice of a) tableau."""
 
     CHUNK = 64
+    FIRST_CHUNK = 16
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
                  group=None):
@@ -153,8 +154,12 @@ class TableauEngine:
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         left = int(maxiters)
         ctrl = None
+        first = True
         while left > 0:
-            k = min(left, self.CHUNK)
+            # short first chunk (eager launches): small solves end here; later chunks are long enough for
+            # liblpx to replay them as hipGraphs
+            k = min(left, self.FIRST_CHUNK if first else self.CHUNK)
+            first = False
             self.enqueue(k)
             left -= k
             ctrl = self.read_ctrl()
