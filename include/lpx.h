@@ -52,6 +52,8 @@ extern "C" {
 #define LPX_KIND_PRIMAL 0  /* PrimalRevisedSimplexSolver.solve   primal_solvers.py:176-209 */
 #define LPX_KIND_DUAL 1    /* DualRevisedSimplexSolver.solve     dual_solvers.py:82-108 */
 #define LPX_KIND_BOUNDED 2 /* BoundedVariablePrimalSimplexSolver.solve  special_solvers.py:221-343 */
+#define LPX_KIND_PRIMAL_NAIVE 3 /* PrimalNaiveSimplexSolver.solve: float32 re-inversion per pivot, :92-94, :169-174 */
+#define LPX_KIND_DUAL_NAIVE 4   /* DualNaiveSimplexSolver.solve */
 
 /* Device-resident control block (128 bytes).  Written only by kernels (and by lpx_ctrl_reset); the host
  * reads it with lpx_read_ctrl.  `counter` is the reference's self.counter. */
@@ -93,6 +95,8 @@ typedef struct lpx_revised {
     int64_t log_cap;
     void *workspace;
     int64_t workspace_bytes;
+    void *naive_workspace;  /* naive solvers only (else NULL): lpx_naive_workspace_bytes(m) bytes */
+    int64_t naive_workspace_bytes;
 } lpx_revised;
 
 /* State of one LP in tableau form: T = [B^-1 A | x_B ; rc | -z], (m+1) x ld, carried and updated in place.
@@ -142,6 +146,14 @@ int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *str
 /* PrimalRevisedSimplexSolver.pivot(row, col), primal_solvers.py:255-263 (called from outside the loop by
  * PhaseOneSimplexSolver, special_solvers.py:77-79). */
 int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream);
+
+/* Naive solvers: inv_basis_matrix = inv(A[:, basis]) in float32 (Gauss-Jordan, partial pivoting) and
+ * bfs = inv_basis_matrix @ b, primal_solvers.py:92-94 and :68-70 (the reference calls LAPACK through
+ * np.linalg.inv; rounding differs in the last float32 bits). */
+int64_t lpx_naive_workspace_bytes(int64_t m);
+int lpx_revised_reinvert(const lpx_revised *s, void *stream);
+/* PrimalNaiveSimplexSolver.pivot(row, col), primal_solvers.py:169-174: basis[row] = col, re-invert, bfs. */
+int lpx_naive_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream);
 
 /* _get_bfs_expanded + _calc_current_cost, primal_solvers.py:72-79 (bounded: special_solvers.py:201-206):
  * x[n] = scatter of x_B (plus nonbasic bound values when lb/ub are set); cost[0] = dot(c, x). */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblpx.so")
 # status codes (lpx.h)
 RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
 VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
-KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED = 0, 1, 2
+KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE = 0, 1, 2, 3, 4
 
 vp = C.c_void_p
 i64 = C.c_int64
@@ -42,6 +42,7 @@ class LpxRevised(C.Structure):
         ("lb", vp), ("ub", vp), ("ctrl", vp),
         ("log", vp), ("log_cap", i64),
         ("workspace", vp), ("workspace_bytes", i64),
+        ("naive_workspace", vp), ("naive_workspace_bytes", i64),
     ]
 
 
@@ -65,6 +66,9 @@ _SIGS = {
     "lpx_revised_workspace_bytes": (i64, [i64, i64]),
     "lpx_revised_iterate": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
     "lpx_revised_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),
+    "lpx_naive_workspace_bytes": (i64, [i64]),
+    "lpx_revised_reinvert": (C.c_int, [C.POINTER(LpxRevised), vp]),
+    "lpx_naive_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),
     "lpx_revised_expand": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp]),
     "lpx_bounded_update_bfs": (C.c_int, [C.POINTER(LpxRevised), vp]),
     "lpx_revised_reduced_costs": (C.c_int, [C.POINTER(LpxRevised), C.c_int, vp, vp]),

@@ -559,6 +559,7 @@ enum { PREP_PRIMAL = 0, PREP_DUAL = 1, PREP_BOUNDED = 2, PREP_FORCED = 3 };
 struct PrepArgs {
     lpx_revised s;
     int kind;
+    int naive; // naive solvers: basis change only (no eta / pivot-row copy), the state stays float32
     int64_t forced_r;
     int64_t nratio;
     Partials ratio;
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_prepare(PrepArgs a)
 
     const double dr = a.d[r];
     const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    if (gi < m) a.e[gi] = (gi == r) ? 1.0 / dr : (-a.d[gi]) / dr; // primal_solvers.py:236-244
-    if (gi < lpx_roundup_dev(m, 2)) a.rowr[gi] = a.s.Binv[r * a.s.ldB + gi]; // K1 reads 2-wide: even length <= ldB
+    if (!a.naive && gi < m) a.e[gi] = (gi == r) ? 1.0 / dr : (-a.d[gi]) / dr; // primal_solvers.py:236-244
+    if (!a.naive && gi < lpx_roundup_dev(m, 2)) a.rowr[gi] = a.s.Binv[r * a.s.ldB + gi]; // K1 reads 2-wide: even length <= ldB
     if (lead) {
         const int64_t leaving = a.s.basis[r];
         a.scal[0] = a.s.xB[r];
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_prepare(PrepArgs a)
         ctrl->leave_state = leave_state;
         ctrl->ratio_val = theta;
         ctrl->flip = 0;
-        ctrl->f32_phase = 0; // E is float64 (np.eye): everything is float64 from here on
+        if (!a.naive) ctrl->f32_phase = 0; // E is float64 (np.eye): everything is float64 from here on
     }
 }
 
@@ -726,6 +727,105 @@ __global__ __launch_bounds__(1024) void k_cost(const float *c, const double *x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Naive solvers: float32 re-inversion of the basis after every pivot (primal_solvers.py:92-94) and
+// bfs = inv_basis_matrix @ b (:68-70).  Gauss-Jordan with partial pivoting on W = [B | I] (m x 2m float32);
+// per elimination step one single-workgroup kernel (pivot search, row swap, pivot-row scaling, multiplier column)
+// and one multi-workgroup rank-1 elimination.  The reference re-inverts with LAPACK; this is its O(m^3) slow
+// variant and not a performance path -- correctness (sequence parity) is the bar.
+// ---------------------------------------------------------------------------------------------------------
+struct NaiveWs {
+    float *W, *prow, *colk;
+    int64_t ldw, bytes;
+};
+static NaiveWs naive_ws(int64_t m, void *base)
+{
+    NaiveWs w;
+    char *p = (char *)base;
+    w.ldw = lpx_roundup(2 * m, 4);
+    w.W = (float *)carve(p, 4 * m * w.ldw);
+    w.prow = (float *)carve(p, 4 * w.ldw);
+    w.colk = (float *)carve(p, 4 * (m + 4));
+    w.bytes = (int64_t)(p - (char *)base);
+    return w;
+}
+extern "C" int64_t lpx_naive_workspace_bytes(int64_t m) { return m > 0 ? naive_ws(m, nullptr).bytes : 0; }
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_init(lpx_revised s, NaiveWs w)
+{
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t idx = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const int64_t m = s.m;
+    if (idx >= m * 2 * m) return;
+    const int64_t i = idx / (2 * m), k = idx - i * 2 * m;
+    w.W[i * w.ldw + k] = (k < m) ? s.At[s.basis[k] * s.ldAt + i] : ((k - m) == i ? 1.f : 0.f);
+}
+__global__ __launch_bounds__(1024) void k_inv_pivot(lpx_revised s, NaiveWs w, int64_t k)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t m = s.m;
+    VI best{LPX_INF, LPX_NOIDX}; // argmax |W[i][k]|, i >= k, first on ties
+    for (int64_t i = k + threadIdx.x; i < m; i += blockDim.x) {
+        const double v = -(double)fabsf(w.W[i * w.ldw + k]);
+        if (vi_less(v, i, best.v, best.i)) { best.v = v; best.i = i; }
+    }
+    best = block_argmin(best, red);
+    const int64_t p = best.i;
+    const float piv = w.W[p * w.ldw + k];
+    // swap rows k and p, scale the pivot row; keep it in prow
+    for (int64_t c = threadIdx.x; c < 2 * m; c += blockDim.x) {
+        const float a = w.W[p * w.ldw + c], b = w.W[k * w.ldw + c];
+        const float pr = a / piv;
+        w.prow[c] = pr;
+        w.W[k * w.ldw + c] = pr;
+        if (p != k) w.W[p * w.ldw + c] = b;
+    }
+    __syncthreads();
+    // multiplier column (after the swap), read before the elimination overwrites it
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) w.colk[i] = (i == k) ? 0.f : w.W[i * w.ldw + k];
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_elim(lpx_revised s, NaiveWs w, int64_t k)
+{
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t c = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (c >= 2 * s.m || i == k) return;
+    const float f = w.colk[i];
+    w.W[i * w.ldw + c] = fmaf(-f, w.prow[c], w.W[i * w.ldw + c]);
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_finish(lpx_revised s, NaiveWs w)
+{
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * LPX_WAVES + wave;
+    const int64_t m = s.m;
+    if (i >= m) return;
+    float acc = 0.f; // bfs = inv_basis_matrix @ b in float32
+    for (int64_t k = lane; k < m; k += 64) {
+        const float v = w.W[i * w.ldw + m + k];
+        s.Binv[i * s.ldB + k] = (double)v;
+        acc = fmaf(v, s.b[k], acc);
+    }
+    acc = wave_sum<float>(acc);
+    if (lane == 0) s.xB[i] = (double)acc;
+}
+static int launch_reinvert(const lpx_revised *s, hipStream_t st)
+{
+    LPX_REQUIRE(s->naive_workspace != nullptr && s->naive_workspace_bytes >= lpx_naive_workspace_bytes(s->m),
+                "naive solvers need naive_workspace (lpx_naive_workspace_bytes)");
+    LPX_REQUIRE(s->m <= 65535, "m too large for the re-inversion grid");
+    const NaiveWs w = naive_ws(s->m, s->naive_workspace);
+    const int64_t m = s->m;
+    hipLaunchKernelGGL(k_inv_init, dim3((unsigned)lpx_cdiv(2 * m * m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w);
+    for (int64_t k = 0; k < m; ++k) {
+        hipLaunchKernelGGL(k_inv_pivot, dim3(1), dim3(1024), 0, st, *s, w, k);
+        hipLaunchKernelGGL(k_inv_elim, dim3((unsigned)lpx_cdiv(2 * m, LPX_BLOCK), (unsigned)m), dim3(LPX_BLOCK), 0, st, *s, w, k);
+    }
+    hipLaunchKernelGGL(k_inv_finish, dim3((unsigned)lpx_cdiv(m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st, *s, w);
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host-side drivers
 // ---------------------------------------------------------------------------------------------------------
 static int check_revised(const lpx_revised *s)
@@ -788,10 +888,11 @@ static void launch_direction(const lpx_revised *s, const RevisedWs &w, int kind,
     a.price = w.price; a.ratio = w.ratio; a.d = w.d;
     hipLaunchKernelGGL(k_direction, dim3((unsigned)lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
 }
-static void launch_prepare(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_r, hipStream_t st)
+static void launch_prepare(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_r, hipStream_t st,
+                           int naive = 0)
 {
     PrepArgs a{};
-    a.s = *s; a.kind = kind; a.forced_r = forced_r; a.nratio = lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK);
+    a.s = *s; a.kind = kind; a.naive = naive; a.forced_r = forced_r; a.nratio = lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK);
     a.ratio = w.ratio; a.d = w.d; a.e = w.e; a.rowr = w.rowr; a.scal = w.scal;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)lpx_cdiv(lpx_roundup(s->m, 2), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
 }
@@ -817,7 +918,32 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
 {
     int rc = check_revised(s);
     if (rc) return rc;
-    LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "bad kind");
+    LPX_REQUIRE(kind >= LPX_KIND_PRIMAL && kind <= LPX_KIND_DUAL_NAIVE, "bad kind");
+    if (kind == LPX_KIND_PRIMAL_NAIVE || kind == LPX_KIND_DUAL_NAIVE) {
+        LPX_REQUIRE(s->naive_workspace != nullptr && s->naive_workspace_bytes >= lpx_naive_workspace_bytes(s->m),
+                    "naive solvers need naive_workspace (lpx_naive_workspace_bytes)");
+        const RevisedWs wn = revised_ws(s->m, s->n, s->workspace);
+        hipStream_t st = (hipStream_t)stream;
+        for (int64_t it = 0; it < iters; ++it) {
+            if (kind == LPX_KIND_PRIMAL_NAIVE) {
+                launch_pricing_sums(s, wn, st);
+                launch_fin(s, wn, FIN_PRIMAL, nullptr, st);
+                launch_direction(s, wn, DIR_PRIMAL, -1, st);
+                launch_prepare(s, wn, PREP_PRIMAL, -1, st, 1);
+            } else {
+                hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)s->xB, s->m, s->ctrl);
+                launch_colsum_A(s, wn, W_BINV_ROW, wn.zpart2, st);
+                launch_pricing_sums(s, wn, st);
+                launch_fin(s, wn, FIN_DUAL, nullptr, st);
+                launch_direction(s, wn, DIR_DUAL, -1, st);
+                launch_prepare(s, wn, PREP_DUAL, -1, st, 1);
+            }
+            int rr = launch_reinvert(s, st); // primal_solvers.py:169-174
+            if (rr) return rr;
+        }
+        LPX_LAUNCH_CHECK();
+        return LPX_OK;
+    }
     LPX_REQUIRE(kind != LPX_KIND_BOUNDED || (s->lb && s->ub), "bounded solver needs lb/ub");
     const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
     hipStream_t st0 = (hipStream_t)stream;
@@ -871,6 +997,31 @@ extern "C" int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col,
     launch_direction(s, w, DIR_FORCED, col, st);
     launch_prepare(s, w, PREP_FORCED, row, st);
     launch_update(s, w, true, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_revised_reinvert(const lpx_revised *s, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    rc = launch_reinvert(s, (hipStream_t)stream);
+    if (rc) return rc;
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_naive_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(row >= 0 && row < s->m && col >= 0 && col < s->n, "pivot position out of range");
+    const RevisedWs w = revised_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    launch_direction(s, w, DIR_FORCED, col, st);
+    launch_prepare(s, w, PREP_FORCED, row, st, 1);
+    rc = launch_reinvert(s, st);
+    if (rc) return rc;
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

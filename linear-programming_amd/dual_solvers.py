@@ -24,7 +24,7 @@ class DualNaiveSimplexSolver(PrimalNaiveSimplexSolver):
         """Dual simplex loop (dual_solvers.py:82-108).  ``optimum`` is never reset to False (quirk kept:
         a non-converged dual solve returns ``optimum=None``)."""
         self.counter = 0
-        ctrl = self._engine.run(self._KIND, maxiters)
+        ctrl = self._engine.run(self._device_kind(), maxiters)
         self.counter = int(ctrl.counter)
         if ctrl.status not in (_lib.RUNNING, _lib.OPTIMAL):
             self._sync_basis()

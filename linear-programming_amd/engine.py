@@ -20,7 +20,7 @@ class RevisedEngine:
     CHUNK = 64
     FIRST_CHUNK = 16
 
-    def __init__(self, c32, A32, b32, basis, inv0, bfs0, var_state=None, lb=None, ub=None, log_cap=0):
+    def __init__(self, c32, A32, b32, basis, inv0, bfs0, var_state=None, lb=None, ub=None, log_cap=0, naive=False):
         torch = torch_cuda()
         self.lib = _lib.load()
         self.torch = torch
@@ -61,6 +61,11 @@ class RevisedEngine:
         s.log = self.log.data_ptr() if self.log_cap > 0 else None
         s.log_cap = self.log_cap
         s.workspace, s.workspace_bytes = self.workspace.data_ptr(), ws_bytes
+        self.naive = bool(naive)
+        if self.naive:  # float32 re-inversion scratch: W = [B | I]
+            nbytes = self.lib.lpx_naive_workspace_bytes(m)
+            self.naive_workspace = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            s.naive_workspace, s.naive_workspace_bytes = self.naive_workspace.data_ptr(), nbytes
         _lib.check(self.lib.lpx_ctrl_init(s.ctrl, 1, stream_ptr()))
 
     # ------------------------------------------------------------------ control block
@@ -95,7 +100,11 @@ class RevisedEngine:
         _lib.check(self.lib.lpx_revised_iterate(C.byref(self.s), kind, int(iters), stream_ptr()))
 
     def pivot(self, row, col):
-        _lib.check(self.lib.lpx_revised_pivot(C.byref(self.s), int(row), int(col), stream_ptr()))
+        """Caller-chosen basis change; works whatever state the last solve() ended in (kernels gate on RUNNING)."""
+        st = stream_ptr()
+        _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
+        f = self.lib.lpx_naive_pivot if self.naive else self.lib.lpx_revised_pivot
+        _lib.check(f(C.byref(self.s), int(row), int(col), st))
 
     def bounded_update_bfs(self):
         _lib.check(self.lib.lpx_bounded_update_bfs(C.byref(self.s), stream_ptr()))

@@ -51,7 +51,8 @@ class PrimalNaiveSimplexSolver:
         self.counter = None
         self.optimum = None
         self._check_basis_feasibility(inv32, bfs32)
-        self._engine = RevisedEngine(self.c, self.A, self.b, self.basis, inv32, bfs32, log_cap=self._LOG_CAP)
+        self._engine = RevisedEngine(self.c, self.A, self.b, self.basis, inv32, bfs32, log_cap=self._LOG_CAP,
+                                     naive=self._NAIVE)
 
     # ------------------------------------------------------------------ constructor helpers
     def _preprocess_problem(self, c, A, b):
@@ -100,11 +101,16 @@ class PrimalNaiveSimplexSolver:
         if status == _lib.PRIMAL_UNBOUNDED:
             raise PrimalIsUnboundedError  # primal_solvers.py:130-132
 
+    def _device_kind(self):
+        if self._NAIVE:
+            return {_lib.KIND_PRIMAL: _lib.KIND_PRIMAL_NAIVE, _lib.KIND_DUAL: _lib.KIND_DUAL_NAIVE}[self._KIND]
+        return self._KIND
+
     def solve(self, maxiters: int = 100):
         """Primal simplex loop (primal_solvers.py:176-209); resumes from the current device state."""
         self.counter = 0
         self.optimum = False
-        ctrl = self._engine.run(self._KIND, maxiters)
+        ctrl = self._engine.run(self._device_kind(), maxiters)
         self.counter = int(ctrl.counter)
         if ctrl.status not in (_lib.RUNNING, _lib.OPTIMAL):
             self._sync_basis()

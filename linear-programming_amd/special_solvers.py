@@ -71,6 +71,7 @@ class BoundedVariablePrimalSimplexSolver(PrimalRevisedSimplexSolver):
     """Primal simplex for lb <= x <= ub without bound rows (special_solvers.py:94-343)."""
 
     _KIND = _lib.KIND_BOUNDED
+    _NAIVE = False
 
     def __init__(self, c, A, b, lb, ub, basis, lb_nonbasic_vars, ub_nonbasic_vars):
         self.c, self.A, self.b = self._preprocess_problem(c, A, b)
