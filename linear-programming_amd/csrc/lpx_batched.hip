@@ -29,7 +29,7 @@ struct BatchLds {
     double *Binv; // m x ldb
     float *A;     // m x n
     double *xB, *y, *rc, *d, *e, *rowr;
-    float *c;
+    float *c, *cb; // cb[i] = c[basis[i]]
     int *basis;
     int *vstate;
     int64_t ldb;
@@ -54,52 +54,91 @@ __host__ __device__ static inline BatchLds batch_lds(int64_t m, int64_t n, char 
     L.rowr = (double *)take(8 * m);
     L.A = (float *)take(4 * m * n);
     L.c = (float *)take(4 * n);
+    L.cb = (float *)take(4 * m);
     L.basis = (int *)take(4 * m);
     L.vstate = (int *)take(4 * n);
     L.bytes = (int64_t)(p - base);
     return L;
 }
 
-template <typename AccT>
-__device__ __forceinline__ void batch_price(const BatchLds &L, int m, int n, int t)
+// Workgroup reductions for the batched kernel: (value, 32-bit index) pairs, the independent shuffles of one round
+// issued together, one barrier pair per reduction.  numpy semantics: first index of the extreme value.
+struct BatchRed {
+    double v[LPX_WAVES], w[LPX_WAVES];
+    int i[LPX_WAVES];
+};
+// min of v and (independently) min of idx over the workgroup
+__device__ __forceinline__ void batch_min_imin(double &v, int &idx, BatchRed &red)
 {
-    // y = c_B @ B^-1 (primal_solvers.py:64, first product), one lane per column, i ascending
-    if (t < m) {
-        AccT acc = (AccT)0;
-        for (int i = 0; i < m; ++i) acc = fma((AccT)L.c[L.basis[i]], (AccT)L.Binv[i * L.ldb + t], acc);
-        L.y[t] = (double)acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        v = fmin(v, ov);
+        idx = oi < idx ? oi : idx;
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red.v[wv] = v; red.i[wv] = idx; }
+    __syncthreads();
+    v = red.v[0]; idx = red.i[0];
+#pragma unroll
+    for (int k = 1; k < LPX_WAVES; ++k) {
+        v = fmin(v, red.v[k]);
+        idx = red.i[k] < idx ? red.i[k] : idx;
     }
     __syncthreads();
-    // rc = c - y @ A ; rc[basis] = 0 (:64-65)
-    if (t < n) {
-        AccT acc = (AccT)0;
-        for (int i = 0; i < m; ++i) acc = fma((AccT)L.y[i], (AccT)L.A[i * n + t], acc);
-        double rc = (double)((AccT)L.c[t] - acc);
-        if (L.vstate[t] == LPX_VS_BASIC) rc = 0.0;
-        L.rc[t] = rc;
+}
+// lexicographic argmin of (v, idx) and (independently) max of w over the workgroup
+__device__ __forceinline__ void batch_argmin_max(double &v, int &idx, double &w, BatchRed &red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off), ow = __shfl_xor(w, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        w = fmax(w, ow);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red.v[wv] = v; red.i[wv] = idx; red.w[wv] = w; }
+    __syncthreads();
+    v = red.v[0]; idx = red.i[0]; w = red.w[0];
+#pragma unroll
+    for (int k = 1; k < LPX_WAVES; ++k) {
+        if (red.v[k] < v || (red.v[k] == v && red.i[k] < idx)) { v = red.v[k]; idx = red.i[k]; }
+        w = fmax(w, red.w[k]);
     }
     __syncthreads();
 }
 
-template <typename AccT>
-__device__ __forceinline__ void batch_direction(const BatchLds &L, int m, int n, int t, int j)
+// Sequential dot product acc = fma(a_k, b_k, acc), k ascending (the oracle's order), with the LDS loads of 8
+// steps issued ahead of the 8 dependent fmas so that LDS latency overlaps the fma chain.
+template <typename AccT, typename TA, typename TB>
+__device__ __forceinline__ AccT batch_dot(const TA *pa, int sa, const TB *pb, int sb, int len)
 {
-    // d = B^-1 @ A[:, j] (:129), one lane per row, k ascending
-    if (t < m) {
-        AccT acc = (AccT)0;
-        for (int k = 0; k < m; ++k) acc = fma((AccT)L.Binv[t * L.ldb + k], (AccT)L.A[k * n + j], acc);
-        L.d[t] = (double)acc;
+    AccT acc = (AccT)0;
+    int k = 0;
+    for (; k + 8 <= len; k += 8) {
+        AccT x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = (AccT)pa[(k + u) * sa];
+            y[u] = (AccT)pb[(k + u) * sb];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(x[u], y[u], acc);
     }
-    __syncthreads();
+    for (; k < len; ++k) acc = fma((AccT)pa[k * sa], (AccT)pb[k * sb], acc);
+    return acc;
 }
 
 __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ BlockRed red;
+    __shared__ BatchRed red;
     const int m = (int)a.m, n = (int)a.n, t = threadIdx.x;
     const int64_t lp = blockIdx.x;
     const BatchLds L = batch_lds(m, n, smem);
+    const int ldb = (int)L.ldb;
 
     // ---- load the LP into LDS
     const float *gA = a.A + lp * (int64_t)m * n;
@@ -108,18 +147,24 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
         L.c[idx] = a.c[lp * n + idx];
         L.vstate[idx] = LPX_VS_LOWER;
     }
-    for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
-        const int i = idx / m, k = idx - i * m;
-        L.Binv[i * L.ldb + k] = a.Binv0 ? (double)a.Binv0[lp * (int64_t)m * m + idx] : (i == k ? 1.0 : 0.0);
+    {
+        int i = t / m, k = t - i * m; // incremental (row, col) walk: no division in the loop
+        const int di = LPX_BLOCK / m, dk = LPX_BLOCK - di * m;
+        for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
+            L.Binv[i * ldb + k] = a.Binv0 ? (double)a.Binv0[lp * (int64_t)m * m + idx] : (i == k ? 1.0 : 0.0);
+            i += di; k += dk;
+            if (k >= m) { k -= m; i += 1; }
+        }
     }
     if (t < m) L.basis[t] = (int)a.basis[lp * m + t];
     __syncthreads();
-    if (t < m) L.vstate[L.basis[t]] = LPX_VS_BASIC;
-    // bfs = inv_basis_matrix @ b in float32 (primal_solvers.py:38)
     if (t < m) {
-        float acc = 0.f;
-        for (int k = 0; k < m; ++k) acc = fmaf((float)L.Binv[t * L.ldb + k], a.b[lp * m + k], acc);
-        L.xB[t] = (double)acc;
+        L.vstate[L.basis[t]] = LPX_VS_BASIC;
+        L.cb[t] = L.c[L.basis[t]];
+        // bfs = inv_basis_matrix @ b in float32 (primal_solvers.py:38)
+        float s0 = 0.f;
+        for (int k = 0; k < m; ++k) s0 = fmaf((float)L.Binv[t * ldb + k], a.b[lp * m + k], s0);
+        L.xB[t] = (double)s0;
     }
     __syncthreads();
 
@@ -128,39 +173,61 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
     int64_t counter = 0, pivots = 0;
     while (counter < a.maxiters) { // primal_solvers.py:191
         counter += 1;
-        if (f32) batch_price<float>(L, m, n, t);
-        else batch_price<double>(L, m, n, t);
-        const double rcv = (t < n) ? L.rc[t] : LPX_INF;
-        const double mn = block_min(rcv, red);
-        const int j = (int)block_imin((t < n && rcv < 0.0) ? t : LPX_NOIDX, red);
+        // ---- y_t = (c_B @ B^-1)_t (:64, first product): one lane per column, i ascending
+        if (t < m)
+            L.y[t] = f32 ? (double)batch_dot<float>(L.cb, 1, L.Binv + t, ldb, m)
+                         : (double)batch_dot<double>(L.cb, 1, L.Binv + t, ldb, m);
+        __syncthreads();
+        // ---- rc_t = c_t - (y @ A)_t ; rc[basis] = 0 (:64-65); min and first negative (:135-142)
+        double mn = LPX_INF;
+        int j = 0x7FFFFFFF;
+        if (t < n) {
+            double rc = f32 ? (double)(L.c[t] - batch_dot<float>(L.y, 1, L.A + t, n, m))
+                            : (double)L.c[t] - batch_dot<double>(L.y, 1, L.A + t, n, m);
+            if (L.vstate[t] == LPX_VS_BASIC) rc = 0.0;
+            mn = rc;
+            if (rc < 0.0) j = t;
+        }
+        batch_min_imin(mn, j, red);
         if (lpx_is_optimal_min(mn)) { // :140-142
             status = LPX_OPTIMAL;
             break;
         }
-        if (f32) batch_direction<float>(L, m, n, t, j);
-        else batch_direction<double>(L, m, n, t, j);
-        const double di = (t < m) ? L.d[t] : -LPX_INF;
-        VI th{(t < m) ? lpx_psd(L.xB[t], di, f32) : LPX_INF, (t < m) ? t : LPX_NOIDX};
-        th = block_argmin(th, red); // :165-166
-        const double dmax = block_max(di, red);
-        if (dmax <= 0.0) { // :144-147
+        // ---- d_t = (B^-1 @ A[:, j])_t (:129): one lane per row, k ascending; ratios (:165), max(d) (:146)
+        double di = -LPX_INF, th = LPX_INF, dmax = -LPX_INF;
+        int r = 0x7FFFFFFF;
+        if (t < m) {
+            di = f32 ? (double)batch_dot<float>(L.Binv + t * ldb, 1, L.A + j, n, m)
+                     : (double)batch_dot<double>(L.Binv + t * ldb, 1, L.A + j, n, m);
+            L.d[t] = di;
+            th = lpx_psd(L.xB[t], di, f32);
+            r = t;
+            dmax = di;
+        }
+        batch_argmin_max(th, r, dmax, red); // np.argmin: first minimum (:166)
+        if (dmax <= 0.0) {                  // :144-147
             status = LPX_PRIMAL_UNBOUNDED;
             break;
         }
-        const int r = (int)th.i;
         const double dr = L.d[r];
-        if (t < m) {
-            L.e[t] = (t == r) ? 1.0 / dr : (-L.d[t]) / dr; // :236-244
-            L.rowr[t] = L.Binv[r * L.ldb + t];
-        }
         const double xr = L.xB[r];
+        // ---- eta column (:236-244) and copy of the old pivot row
+        if (t < m) {
+            L.e[t] = (t == r) ? 1.0 / dr : (-di) / dr;
+            L.rowr[t] = L.Binv[r * ldb + t];
+        }
         __syncthreads();
-        // B^-1 <- E @ B^-1 ; bfs <- E @ bfs (:247-253) as a rank-1 update
-        for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
-            const int i = idx / m, k = idx - i * m;
-            const double ei = L.e[i];
-            double *p = &L.Binv[i * L.ldb + k];
-            *p = (i == r) ? ei * L.rowr[k] : fma(ei, L.rowr[k], *p);
+        // ---- B^-1 <- E @ B^-1 ; bfs <- E @ bfs (:247-253) as a rank-1 update
+        {
+            int i = t / m, k = t - i * m;
+            const int dstep = LPX_BLOCK / m, kstep = LPX_BLOCK - dstep * m;
+            for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
+                const double ei = L.e[i];
+                double *p = &L.Binv[i * ldb + k];
+                *p = (i == r) ? ei * L.rowr[k] : fma(ei, L.rowr[k], *p);
+                i += dstep; k += kstep;
+                if (k >= m) { k -= m; i += 1; }
+            }
         }
         if (t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]);
         if (t == 0) {
@@ -170,6 +237,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
                 lg[0] = r; lg[1] = j; lg[2] = leaving;
             }
             L.basis[r] = j; // :261
+            L.cb[r] = L.c[j];
             L.vstate[leaving] = LPX_VS_LOWER;
             L.vstate[j] = LPX_VS_BASIC;
         }
@@ -187,9 +255,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
     for (int idx = t; idx < n; idx += LPX_BLOCK) a.x[lp * n + idx] = L.rc[idx];
     if (t < m) a.basis[lp * m + t] = L.basis[t];
     if (t == 0) {
-        double acc = 0.0;
-        for (int jx = 0; jx < n; ++jx) acc = fma((double)L.c[jx], L.rc[jx], acc);
-        a.cost[lp] = acc;
+        double s1 = 0.0;
+        for (int jx = 0; jx < n; ++jx) s1 = fma((double)L.c[jx], L.rc[jx], s1);
+        a.cost[lp] = s1;
         a.status[lp] = status;
         a.iters[lp] = counter;
         a.pivots[lp] = pivots;
