@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch"])
+    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -69,6 +69,8 @@ def main():
 
     if args.workload == "batch":
         return bench_batch(args, rank, world, group)
+    if args.workload.startswith("revised"):
+        return bench_revised(args)
 
     m, n = (20000, 40000) if args.workload == "tableau" else (1000, 2000)
     K, W = args.steps, args.warmup
@@ -196,6 +198,67 @@ def cpu_baseline(args, m, n, A, b, c, basis, solver, kc=None):
             "parity": f"GPU and oracle (row, entering, leaving) sequences identical on these {kc} pivots"}
 
 
+def bench_revised(args):
+    """Revised form (explicit B^-1, the drop-in classes' engine): pivots/s of PrimalRevisedSimplexSolver's loop."""
+    import ctypes as C
+
+    import torch
+
+    from linprog_amd import _lib, problems
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from oracle import oracle as O
+
+    m, n = (1000, 2000) if args.workload == "revised1k" else (10000, 20000)
+    K, W = args.steps, args.warmup
+    A, b, c, basis = problems.gen_primal_columns(m, n, args.seed, 0, n)
+    Solver = type("BenchRevised", (PrimalRevisedSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
+    solver = Solver(c, A, b, basis)
+    eng, lib = solver._engine, _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, st))
+    eng.enqueue(_lib.KIND_PRIMAL, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.enqueue(_lib.KIND_PRIMAL, K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    extra = min(K, 200)
+    _lib.check(lib.lpx_profile_k1(1))
+    eng.enqueue(_lib.KIND_PRIMAL, extra)
+    torch.cuda.synchronize()
+    k1_ms, k1_n = C.c_double(), C.c_int64()
+    _lib.check(lib.lpx_profile_k1_read(C.byref(k1_ms), C.byref(k1_n)))
+    _lib.check(lib.lpx_profile_k1(0))
+    ctrl = eng.read_ctrl()
+    if ctrl.pivots != W + K + extra or ctrl.status != _lib.RUNNING:
+        sys.exit(f"bench invalid: {ctrl.pivots} pivots, status {ctrl.status}")
+    kc = args.cpu_pivots if args.cpu_pivots is not None else (300 if m <= 1000 else 20)
+    cpu = None
+    if kc > 0:
+        o = O.OracleRevised(c, A, b, basis, log_cap=kc + 1)
+        t1 = time.perf_counter()
+        r = o.solve(kc)
+        dc = time.perf_counter() - t1
+        if r.log.tolist() != solver.pivot_log()[:kc].tolist():
+            sys.exit("bench invalid: GPU pivot sequence differs from the oracle's")
+        cpu = {"value": kc / dc, "unit": "pivots/s", "cores": 1, "kind": "port",
+               "sample": f"first {kc} pivots, oracle revised loop (C, single thread)",
+               "parity": f"sequences identical on these {kc} pivots"}
+    k1_s = k1_ms.value / 1e3 / max(1, k1_n.value)
+    iter_bytes = 8.0 * (4 * m * m + m * n / 2)  # 16m^2 update + 8m^2 y + 8m^2 direction + 4mn pricing (float32 A)
+    out = {"metric": f"simplex pivots/sec ({m}x{n} revised form, fp64 B^-1)", "value": K / dt, "unit": "pivots/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"gen_primal_columns(m={m}, n={n}, seed={args.seed}) PrimalRevisedSimplexSolver loop",
+                      "m": m, "n": n, "form": "revised"},
+           "roofline": {"bound": "hbm", "kernel": "k_rank1<revised>", "achieved": 16.0 * m * m / k1_s / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 16.0 * m * m / k1_s / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "avg_launch_ms": k1_s * 1e3,
+                        "whole_iteration_GBs": iter_bytes * K / dt / 1e9},
+           "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+
+
 def bench_batch(args, rank, world, group):
     """Config 3: 4096 x gen_primal(64, 128, seed) full solves, sharded by LP index (weak: per-GPU count fixed)."""
     import torch
@@ -238,6 +301,17 @@ def bench_batch(args, rank, world, group):
                       "pivots_per_step_per_gpu": piv, "all_optimal": ok},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None, "note": "LDS-resident; pivots/s = %.3e" % (piv * world * args.steps / dt)}}
+    if rank == 0 and world == 1 and (args.cpu_pivots is None or args.cpu_pivots > 0):
+        from oracle import oracle as O
+
+        nlp = 64
+        t1 = time.perf_counter()
+        for p in probs[:nlp]:
+            O.OracleRevised(*p, log_cap=4).solve(100000)
+        dc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": nlp / dc, "unit": "LPs/s", "cores": 1, "kind": "port",
+                               "sample": f"first {nlp} LPs of the batch, oracle revised loop (C, single thread, "
+                                         f"includes the Python constructor)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

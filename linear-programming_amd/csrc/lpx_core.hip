@@ -77,14 +77,19 @@ extern "C" int lpx_profile_k1_read(double *total_ms, int64_t *launches)
 // ---------------------------------------------------------------------------------------------------------
 struct ColsumPlan {
     int64_t nstrips, nch, rpc;
+    int threads;
 };
-// V = columns per lane (16-byte vector): 2 for fp64 matrices, 4 for fp32
+// V = columns per lane (16-byte vector): 2 for fp64 matrices, 4 for fp32.
+// Row chunks are capped at 32 so that the finishing pass (one lane sums a column's partials) stays short; for
+// small matrices the workgroup is narrowed (64/128 lanes) until there are enough workgroups to occupy the chip.
 static inline ColsumPlan colsum_plan(int64_t rows, int64_t cols, int V)
 {
     ColsumPlan p;
-    p.nstrips = lpx_cdiv(cols, (int64_t)LPX_BLOCK * V);
+    p.threads = LPX_BLOCK;
+    while (p.threads > 64 && lpx_cdiv(cols, (int64_t)p.threads * V) * 32 < 512) p.threads /= 2;
+    p.nstrips = lpx_cdiv(cols, (int64_t)p.threads * V);
     int64_t nch = lpx_cdiv(1024, p.nstrips);
-    if (nch > 256) nch = 256;
+    if (nch > 32) nch = 32;
     if (nch < 1) nch = 1;
     p.rpc = lpx_cdiv(rows, nch);
     if (p.rpc < 4) p.rpc = 4;
@@ -190,7 +195,7 @@ extern "C" int lpx_read_ctrl(const lpx_ctrl *dev_ctrl, lpx_ctrl *host_ctrl, void
 // primal_solvers.py:64 evaluates  c[basis] @ inv_basis_matrix @ A  left to right; dual_solvers.py:37-39.
 // HBM-bound: M is read once (8 m^2 B for B^-1, 4 m n B for the float32 A).
 // ---------------------------------------------------------------------------------------------------------
-enum { W_CB = 0, W_VEC = 1, W_BINV_ROW = 2 };
+enum { W_CB = 0, W_VEC = 1, W_BINV_ROW = 2, W_YPART = 3 };
 struct ColsumArgs {
     const void *M;
     int64_t ld, rows, cols, rpc;
@@ -203,6 +208,10 @@ struct ColsumArgs {
     double *part;
     int64_t ldp;
     const lpx_ctrl *ctrl;
+    // W_YPART: the weights are y = c_B B^-1, still in the form of the row-chunk partials of the preceding
+    // column-sum launch over B^-1; each workgroup finishes the y_i of its own rows into LDS first
+    const double *ypart;
+    int64_t ynch, yld;
 };
 
 template <typename AccT>
@@ -213,14 +222,39 @@ __device__ __forceinline__ AccT colsum_weight(const ColsumArgs &a, int64_t i, in
     return (AccT)a.Binv[r * a.ldB + i];
 }
 
+// sum of a column's partials in chunk order (fixed => deterministic); loads issued 8 ahead of the adds
+template <typename AccT>
+__device__ __forceinline__ AccT fin_sum(const double *part, int64_t nch, int64_t ldp, int64_t col)
+{
+    AccT s = (AccT)0;
+    const double *p = part + col;
+    int64_t ch = 0;
+    for (; ch + 8 <= nch; ch += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(ch + u) * ldp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (AccT)v[u];
+    }
+    for (; ch < nch; ++ch) s += (AccT)p[ch * ldp];
+    return s;
+}
+
 template <typename MatT, typename AccT, int V>
 __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
 {
     typedef MatT vec_t __attribute__((ext_vector_type(V)));
-    const int64_t col = ((int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x) * V;
-    if (col >= a.cols) return;
+    extern __shared__ __attribute__((aligned(16))) char colsum_lds[];
+    AccT *wl = (AccT *)colsum_lds;
+    const int64_t col = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     const int64_t row0 = (int64_t)blockIdx.y * a.rpc;
     const int64_t row1 = (row0 + a.rpc < a.rows) ? row0 + a.rpc : a.rows;
+    const bool lds_w = a.wmode == W_YPART;
+    if (lds_w) {
+        for (int64_t i = row0 + threadIdx.x; i < row1; i += blockDim.x) wl[i - row0] = fin_sum<AccT>(a.ypart, a.ynch, a.yld, i);
+        __syncthreads();
+    }
+    if (col >= a.cols) return;
     const int64_t r = (a.wmode == W_BINV_ROW) ? a.ctrl->leave_r : 0;
     AccT acc[V];
 #pragma unroll
@@ -232,8 +266,13 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
         const vec_t x1 = *(const vec_t *)(p + a.ld);
         const vec_t x2 = *(const vec_t *)(p + 2 * a.ld);
         const vec_t x3 = *(const vec_t *)(p + 3 * a.ld);
-        const AccT w0 = colsum_weight<AccT>(a, i, r), w1 = colsum_weight<AccT>(a, i + 1, r);
-        const AccT w2 = colsum_weight<AccT>(a, i + 2, r), w3 = colsum_weight<AccT>(a, i + 3, r);
+        AccT w0, w1, w2, w3;
+        if (lds_w) {
+            w0 = wl[i - row0]; w1 = wl[i + 1 - row0]; w2 = wl[i + 2 - row0]; w3 = wl[i + 3 - row0];
+        } else {
+            w0 = colsum_weight<AccT>(a, i, r); w1 = colsum_weight<AccT>(a, i + 1, r);
+            w2 = colsum_weight<AccT>(a, i + 2, r); w3 = colsum_weight<AccT>(a, i + 3, r);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             acc[v] = fma(w0, (AccT)x0[v], acc[v]);
@@ -245,7 +284,7 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
     }
     for (; i < row1; ++i) {
         const vec_t x0 = *(const vec_t *)p;
-        const AccT w0 = colsum_weight<AccT>(a, i, r);
+        const AccT w0 = lds_w ? wl[i - row0] : colsum_weight<AccT>(a, i, r);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = fma(w0, (AccT)x0[v], acc[v]);
         p += a.ld;
@@ -285,14 +324,6 @@ struct FinArgs {
     Partials P;
     const lpx_ctrl *ctrl;
 };
-
-template <typename AccT>
-__device__ __forceinline__ AccT fin_sum(const double *part, int64_t nch, int64_t ldp, int64_t col)
-{
-    AccT s = (AccT)0;
-    for (int64_t ch = 0; ch < nch; ++ch) s += (AccT)part[ch * ldp + col];
-    return s;
-}
 
 __global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
 {
@@ -412,14 +443,21 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_dual_select(const double *xB, int
 // transposed copy At (contiguous).  8 m^2 B of HBM traffic.
 // ---------------------------------------------------------------------------------------------------------
 enum { DIR_PRIMAL = 0, DIR_DUAL = 1, DIR_BOUNDED = 2, DIR_FORCED = 3 };
-#define DIR_ROWS_PER_WAVE 4
-#define DIR_ROWS_PER_BLOCK (DIR_ROWS_PER_WAVE * LPX_WAVES)
+// rows per wave: 1 while the per-workgroup ratio partials fit their arrays (more, smaller workgroups fill the chip
+// at m ~ 1000), more for very tall matrices
+static inline int dir_rows_per_wave(int64_t m)
+{
+    int rpw = 1;
+    while (lpx_cdiv(m, (int64_t)rpw * LPX_WAVES) > LPX_MAXP) rpw *= 2;
+    return rpw;
+}
 
 struct DirArgs {
     lpx_revised s;
     int kind;
     int64_t forced_j;
     int64_t nprice; // number of pricing partials
+    int rpw;        // rows per wave
     Partials price, ratio;
     double *d;
 };
@@ -503,10 +541,10 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_direction(DirArgs a)
     const int64_t m = a.s.m;
     const float *aj = a.s.At + j * a.s.ldAt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t rbase = (int64_t)blockIdx.x * DIR_ROWS_PER_BLOCK + wave * DIR_ROWS_PER_WAVE;
+    const int64_t rbase = ((int64_t)blockIdx.x * LPX_WAVES + wave) * a.rpw;
     VI t1{LPX_INF, LPX_NOIDX}, t2{LPX_INF, LPX_NOIDX};
     double dmax = -LPX_INF;
-    for (int q = 0; q < DIR_ROWS_PER_WAVE; ++q) {
+    for (int q = 0; q < a.rpw; ++q) {
         const int64_t i = rbase + q;
         if (i >= m) break; // wave-uniform
         const double *Bi = a.s.Binv + i * a.s.ldB;
@@ -841,8 +879,7 @@ static int check_revised(const lpx_revised *s)
                 "A, At, Binv and workspace must be 16-byte aligned");
     LPX_REQUIRE(s->workspace != nullptr && s->workspace_bytes >= lpx_revised_workspace_bytes(s->m, s->n),
                 "workspace too small (see lpx_revised_workspace_bytes)");
-    LPX_REQUIRE(lpx_cdiv(s->n, LPX_BLOCK) <= LPX_MAXP && lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK) <= LPX_MAXP,
-                "problem too large for the partial arrays (n <= 524288, m <= 32768)");
+    LPX_REQUIRE(lpx_cdiv(s->n, LPX_BLOCK) <= LPX_MAXP, "problem too large for the partial arrays (n <= 524288)");
     return LPX_OK;
 }
 
@@ -852,7 +889,7 @@ static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_
     a.M = s->Binv; a.ld = s->ldB; a.rows = s->m; a.cols = s->m; a.rpc = w.py.rpc;
     a.wmode = W_CB; a.c = s->c; a.basis = s->basis;
     a.part = w.ypart; a.ldp = w.ldyp; a.ctrl = s->ctrl;
-    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(LPX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), 0, st, a);
 }
 static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
 {
@@ -860,7 +897,9 @@ static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode,
     a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = s->n; a.rpc = w.pa.rpc;
     a.wmode = wmode; a.wvec = w.y; a.Binv = s->Binv; a.ldB = s->ldB;
     a.part = part; a.ldp = w.ldzp; a.ctrl = s->ctrl;
-    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+    a.ypart = w.ypart; a.ynch = w.py.nch; a.yld = w.ldyp;
+    const size_t lds = (wmode == W_YPART) ? (size_t)w.pa.rpc * sizeof(double) : 0;
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), lds, st, a);
 }
 static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, double *rc_out, hipStream_t st)
 {
@@ -874,25 +913,30 @@ static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, doubl
     }
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(a.cols, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
 }
-// y = c_B B^-1, z = y A  (3 launches)
+// y = c_B B^-1 (row-chunk partials), z = y A with y finished inside the second launch (2 launches)
 static void launch_pricing_sums(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
 {
     launch_colsum_B(s, w, st);
-    launch_fin(s, w, FIN_Y, nullptr, st);
-    launch_colsum_A(s, w, W_VEC, w.zpart, st);
+    if ((size_t)w.pa.rpc * sizeof(double) <= 48 * 1024) {
+        launch_colsum_A(s, w, W_YPART, w.zpart, st);
+    } else { // very tall matrices: finish y in its own launch
+        launch_fin(s, w, FIN_Y, nullptr, st);
+        launch_colsum_A(s, w, W_VEC, w.zpart, st);
+    }
 }
 static void launch_direction(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_j, hipStream_t st)
 {
     DirArgs a{};
     a.s = *s; a.kind = kind; a.forced_j = forced_j; a.nprice = lpx_cdiv(s->n, LPX_BLOCK);
+    a.rpw = dir_rows_per_wave(s->m);
     a.price = w.price; a.ratio = w.ratio; a.d = w.d;
-    hipLaunchKernelGGL(k_direction, dim3((unsigned)lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_direction, dim3((unsigned)lpx_cdiv(s->m, (int64_t)a.rpw * LPX_WAVES)), dim3(LPX_BLOCK), 0, st, a);
 }
 static void launch_prepare(const lpx_revised *s, const RevisedWs &w, int kind, int64_t forced_r, hipStream_t st,
                            int naive = 0)
 {
     PrepArgs a{};
-    a.s = *s; a.kind = kind; a.naive = naive; a.forced_r = forced_r; a.nratio = lpx_cdiv(s->m, DIR_ROWS_PER_BLOCK);
+    a.s = *s; a.kind = kind; a.naive = naive; a.forced_r = forced_r; a.nratio = lpx_cdiv(s->m, (int64_t)dir_rows_per_wave(s->m) * LPX_WAVES);
     a.ratio = w.ratio; a.d = w.d; a.e = w.e; a.rowr = w.rowr; a.scal = w.scal;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)lpx_cdiv(lpx_roundup(s->m, 2), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
 }
@@ -1144,7 +1188,7 @@ extern "C" int lpx_pd_admissible(const lpx_revised *s, const double *y, const do
     ColsumArgs a{};
     a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = n_orig; a.rpc = w.pa.rpc;
     a.wmode = W_VEC; a.wvec = y; a.part = w.zpart; a.ldp = w.ldzp; a.ctrl = scr;
-    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), 0, st, a);
     PdArgs p{};
     p.n_orig = n_orig; p.nch = w.pa.nch; p.ldp = w.ldzp; p.m = s->m; p.part = w.zpart; p.c64 = c64; p.v = v;
     p.var_state = s->var_state;
@@ -1167,14 +1211,14 @@ extern "C" int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c
     ColsumArgs b{};
     b.M = s->Binv; b.ld = s->ldB; b.rows = s->m; b.cols = s->m; b.rpc = w.py.rpc;
     b.wmode = W_CB; b.c = s->c; b.basis = s->basis; b.part = w.ypart; b.ldp = w.ldyp; b.ctrl = scr;
-    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(LPX_BLOCK), 0, st, b);
+    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), 0, st, b);
     FinArgs f{};
     f.mode = FIN_Y; f.ctrl = scr; f.cols = s->m; f.nch = w.py.nch; f.ldp = w.ldyp; f.part = w.ypart; f.out = w.y;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, f);
     ColsumArgs a{};
     a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = n_orig; a.rpc = w.pa.rpc;
     a.wmode = W_VEC; a.wvec = w.y; a.part = w.zpart; a.ldp = w.ldzp; a.ctrl = scr;
-    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(LPX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), 0, st, a);
     PdArgs p{};
     p.n_orig = n_orig; p.nch = w.pa.nch; p.ldp = w.ldzp; p.m = s->m; p.part = w.zpart; p.c64 = c64;
     p.var_state = s->var_state; p.vprev = v; p.yrp = w.y; p.P = w.price;
