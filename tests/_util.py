@@ -37,6 +37,10 @@ def case_id(cs):
 def problem_of(cs):
     """(c, A, b, basis) of a base-solver golden case."""
     if "gen" in cs:
+        if cs["gen"] == "gen_dual_unbounded":
+            c, A, b, basis = gen.gen_primal(cs["m"], cs["n"], cs["seed"])
+            b[3] = -1.5
+            return np.abs(c), A, b, basis
         if cs["gen"] == "gen_primal_negG":
             c, A, b, basis = gen.gen_primal(cs["m"], cs["n"], cs["seed"])
             A[:, : cs["n"] - cs["m"]] *= -1

@@ -232,6 +232,24 @@ def random_cases(large):
     A[:, :8] *= -1
     out.append(dict(gen="gen_primal_negG", solver="PrimalRevisedSimplexSolver", m=8, n=16, seed=0, maxiters=100,
                     ref=run_base(PR, c, A, b, basis, 100)))
+    # dual unbounded (primal infeasible): nonnegative row with negative right-hand side, c >= 0
+    for m_, seed_ in ((8, 0), (16, 1)):
+        c, A, b, basis = gen.gen_primal(m_, 2 * m_, seed_)
+        c = np.abs(c)
+        b[3] = -1.5
+        out.append(dict(gen="gen_dual_unbounded", solver="DualRevisedSimplexSolver", m=m_, n=2 * m_, seed=seed_,
+                        maxiters=1000, ref=run_base(DR, c, A, b, basis, 1000)))
+        with Trace() as tr:
+            try:
+                res = special_solvers.PrimalDualAlgorithm(c, A, b).solve(1000, 1000)
+                r = _res(res, tr.events)
+            except Exception as e:
+                r = _res(None, tr.events, type(e).__name__)
+        out.append(dict(gen="gen_dual_unbounded", solver="PrimalDualAlgorithm", m=m_, n=2 * m_, seed=seed_, ref=r))
+    # odd shapes (padding paths of the device layouts)
+    for m_, n_, seed_ in ((1, 2, 0), (3, 5, 1), (5, 11, 2), (7, 9, 3), (33, 67, 4)):
+        add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, m_, n_, seed_, 100000)
+        add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, m_, n_, seed_, 100000)
     if large:
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 256, 512, 0, 100000, keep_x=False)
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 1000, 2000, 0, 400, keep_x=False)
@@ -271,22 +289,26 @@ def primal_dual_cases():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also m=256 full solve and m=1000/2000 prefixes (minutes)")
+    ap.add_argument("--only", default=None, help="write only this fixture file (e.g. random.json)")
     args = ap.parse_args()
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],
                 note="generated by importing the reference in the build container; data only")
 
     def dump(name, cases):
+        if args.only and name != args.only:
+            return
+        cases = cases()
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(dict(meta=meta, cases=cases), f)
         print("wrote", name, len(cases), "cases", flush=True)
 
-    dump("textbook.json", textbook_cases())
-    dump("diet.json", [diet_case()])
-    dump("bounded.json", bounded_cases())
-    dump("primal_dual.json", primal_dual_cases())
-    dump("random.json", random_cases(False))
+    dump("textbook.json", textbook_cases)
+    dump("diet.json", lambda: [diet_case()])
+    dump("bounded.json", bounded_cases)
+    dump("primal_dual.json", primal_dual_cases)
+    dump("random.json", lambda: random_cases(False))
     if args.large:
-        dump("random_large.json", random_cases(True)[-3:])
+        dump("random_large.json", lambda: random_cases(True)[-3:])
 
 
 if __name__ == "__main__":

@@ -222,3 +222,16 @@ def test_full_size_config2_properties():
     assert res.x.min() >= -1e-12 and len(set(res.basis.tolist())) == 1000
     assert_close(res.cost, o.cost, "cost")
     assert_close(res.x, o.x, "x")
+
+
+def test_primal_dual_on_infeasible_primal_does_not_crash():
+    """The reference cannot raise DualIsUnboundedError while an artificial is basic (its y_rp component is 1 > 0,
+    special_solvers.py:435) and then dies with IndexError at :449-452 (golden: gen_dual_unbounded).  The device path
+    follows the same arithmetic (theta = inf) and reports a non-optimal result instead of crashing."""
+    from linprog_amd.special_solvers import PrimalDualAlgorithm
+
+    cs = [c for c in load("random.json") if c["gen"] == "gen_dual_unbounded" and c["solver"] == "PrimalDualAlgorithm"][0]
+    assert cs["ref"]["exception"] == "IndexError"
+    c, A, b, _ = problem_of(cs)
+    res = PrimalDualAlgorithm(c, A, b).solve(12, 100)
+    assert res.optimum is False and res.iters == 12
