@@ -48,6 +48,13 @@ extern "C" {
 #define LPX_VS_UPPER 2    /* nonbasic at its upper bound (bounded-variable solver) */
 #define LPX_VS_EXCLUDED 3 /* column outside the restricted primal (primal-dual algorithm) */
 
+/* lpx_tableau.pricing.  The reference has exactly one entering rule in its standard-form solvers: the first
+ * column with a negative reduced cost (primal_solvers.py:135-138).  LPX_PRICE_DANTZIG (most negative reduced cost,
+ * lowest index on ties) is the build's opt-in extension for large solves; it has no counterpart in the reference
+ * ("parity unpinned"): it is checked against the oracle's restatement of the same rule only. */
+#define LPX_PRICE_FIRST_NEGATIVE 0
+#define LPX_PRICE_DANTZIG 1
+
 /* lpx_revised_iterate `kind` */
 #define LPX_KIND_PRIMAL 0  /* PrimalRevisedSimplexSolver.solve   primal_solvers.py:176-209 */
 #define LPX_KIND_DUAL 1    /* DualRevisedSimplexSolver.solve     dual_solvers.py:82-108 */
@@ -107,6 +114,7 @@ typedef struct lpx_tableau {
     int64_t m, n, ld;   /* n = local structural columns; column n of T is x_B; ld >= n+1, multiple of 2 */
     int64_t col0;       /* global index of local column 0 (0 when unpartitioned) */
     int64_t n_global;   /* total structural columns over all ranks */
+    int64_t pricing;    /* LPX_PRICE_FIRST_NEGATIVE (the reference's rule, default) or LPX_PRICE_DANTZIG (opt-in) */
     double *T;
     int64_t *basis;     /* m, global column indices (replicated) */
     int32_t *var_state; /* n (local columns) */

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblpx.so")
 # status codes (lpx.h)
 RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
 VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
+PRICE_FIRST_NEGATIVE, PRICE_DANTZIG = 0, 1
 KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE = 0, 1, 2, 3, 4
 
 vp = C.c_void_p
@@ -48,7 +49,7 @@ class LpxRevised(C.Structure):
 
 class LpxTableau(C.Structure):
     _fields_ = [
-        ("m", i64), ("n", i64), ("ld", i64), ("col0", i64), ("n_global", i64),
+        ("m", i64), ("n", i64), ("ld", i64), ("col0", i64), ("n_global", i64), ("pricing", i64),
         ("T", vp), ("basis", vp), ("var_state", vp), ("ctrl", vp),
         ("log", vp), ("log_cap", i64),
         ("workspace", vp), ("workspace_bytes", i64),

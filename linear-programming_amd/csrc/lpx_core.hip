@@ -385,33 +385,6 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
     }
 }
 
-// combine per-workgroup partials (executed redundantly by every workgroup of the consuming kernel)
-__device__ __forceinline__ VI combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
-{
-    VI b{LPX_INF, LPX_NOIDX};
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
-        if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
-    return block_argmin(b, red);
-}
-__device__ __forceinline__ double combine_min(const double *v, int64_t np, BlockRed &red)
-{
-    double b = LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmin(b, v[k]);
-    return block_min(b, red);
-}
-__device__ __forceinline__ double combine_max(const double *v, int64_t np, BlockRed &red)
-{
-    double b = -LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmax(b, v[k]);
-    return block_max(b, red);
-}
-__device__ __forceinline__ int64_t combine_imin(const int64_t *i, int64_t np, BlockRed &red)
-{
-    int64_t b = LPX_NOIDX;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = i[k] < b ? i[k] : b;
-    return block_imin(b, red);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // K5: dual row selection (single workgroup): min(x_B), first i with x_i < 0     dual_solvers.py:47-54, :95-102
 // ---------------------------------------------------------------------------------------------------------
@@ -748,22 +721,6 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_expand_scatter(const double *xB, 
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
     if (i < m) x[basis[i]] = xB[i];
 }
-// cost = dot(c, x): one workgroup, fixed summation tree (deterministic)
-__global__ __launch_bounds__(1024) void k_cost(const float *c, const double *x, int64_t n, double *cost)
-{
-    __shared__ double part[16];
-    double acc = 0.0;
-    for (int64_t j = threadIdx.x; j < n; j += 1024) acc = fma((double)c[j], x[j], acc);
-    acc = wave_sum<double>(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        *cost = t;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Naive solvers: float32 re-inversion of the basis after every pivot (primal_solvers.py:92-94) and
 // bfs = inv_basis_matrix @ b (:68-70).  Gauss-Jordan with partial pivoting on W = [B | I] (m x 2m float32);

@@ -166,6 +166,50 @@ struct Partials {
     int64_t *i1; // second index
 };
 
+// combine per-workgroup partials (executed redundantly by every workgroup of the consuming kernel)
+__device__ __forceinline__ VI combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
+{
+    VI b{LPX_INF, LPX_NOIDX};
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
+        if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
+    return block_argmin(b, red);
+}
+__device__ __forceinline__ double combine_min(const double *v, int64_t np, BlockRed &red)
+{
+    double b = LPX_INF;
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmin(b, v[k]);
+    return block_min(b, red);
+}
+__device__ __forceinline__ double combine_max(const double *v, int64_t np, BlockRed &red)
+{
+    double b = -LPX_INF;
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmax(b, v[k]);
+    return block_max(b, red);
+}
+__device__ __forceinline__ int64_t combine_imin(const int64_t *i, int64_t np, BlockRed &red)
+{
+    int64_t b = LPX_NOIDX;
+    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = i[k] < b ? i[k] : b;
+    return block_imin(b, red);
+}
+
+// deterministic dot(c, x) by one workgroup of 1024 lanes: lane-strided fma partial sums, fixed reduction tree
+// (primal_solvers.py:77-79, np.dot(c, x))
+static __global__ __launch_bounds__(1024) void k_cost(const float *c, const double *x, int64_t n, double *cost)
+{
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 1024) acc = fma((double)c[j], x[j], acc);
+    acc = wave_sum<double>(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *cost = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // small math
 // ---------------------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@ struct Rank1Args {
     // (last row of M) also reduce it: price_v0[strip] = min rc, price_i0[strip] = first global column with rc<0
     double *price_v0;
     int64_t *price_i0;
+    int pricing;           // LPX_PRICE_FIRST_NEGATIVE: i0 = first column with rc<0 ; LPX_PRICE_DANTZIG: i0 = argmin rc
 };
 
 template <int NT>
@@ -161,13 +162,24 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
             for (int q = 0; q < 2; ++q) {
                 if (col + q < nstruct) {
                     const double rc = lastv[v][q];
-                    mn = fmin(mn, rc);
-                    if (rc < 0.0 && a.col0 + col + q < jn) jn = a.col0 + col + q;
+                    const int64_t gj = a.col0 + col + q;
+                    if (a.pricing == LPX_PRICE_DANTZIG) {
+                        if (vi_less(rc, gj, mn, jn)) { mn = rc; jn = gj; }
+                    } else {
+                        mn = fmin(mn, rc);
+                        if (rc < 0.0 && gj < jn) jn = gj;
+                    }
                 }
             }
         }
-        mn = block_min(mn, red);
-        jn = block_imin(jn, red);
+        if (a.pricing == LPX_PRICE_DANTZIG) {
+            const VI t = block_argmin(VI{mn, jn}, red);
+            mn = t.v;
+            jn = t.i;
+        } else {
+            mn = block_min(mn, red);
+            jn = block_imin(jn, red);
+        }
         if (threadIdx.x == 0) {
             a.price_v0[blockIdx.x] = mn;
             a.price_i0[blockIdx.x] = jn;

@@ -63,6 +63,7 @@ static int check_tableau(const lpx_tableau *s)
     LPX_REQUIRE(lpx_cdiv(s->n, LPX_BLOCK) <= LPX_MAXP && lpx_cdiv(s->m + 1, LPX_BLOCK) <= LPX_MAXP,
                 "problem too large for the partial arrays");
     LPX_REQUIRE(s->col0 >= 0 && s->n_global >= s->col0 + s->n, "bad column partition");
+    LPX_REQUIRE(s->pricing == LPX_PRICE_FIRST_NEGATIVE || s->pricing == LPX_PRICE_DANTZIG, "bad pricing rule");
     return LPX_OK;
 }
 
@@ -78,41 +79,39 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P
     int64_t jn = LPX_NOIDX;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
         const double rc = s.T[s.m * s.ld + j];
-        mn = fmin(mn, rc);
-        if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+        if (s.pricing == LPX_PRICE_DANTZIG) {
+            if (vi_less(rc, s.col0 + j, mn, jn)) { mn = rc; jn = s.col0 + j; }
+        } else {
+            mn = fmin(mn, rc);
+            if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+        }
     }
-    mn = block_min(mn, red);
-    jn = block_imin(jn, red);
+    if (s.pricing == LPX_PRICE_DANTZIG) {
+        const VI t = block_argmin(VI{mn, jn}, red);
+        mn = t.v;
+        jn = t.i;
+    } else {
+        mn = block_min(mn, red);
+        jn = block_imin(jn, red);
+    }
     if (threadIdx.x == 0) {
         P.v0[blockIdx.x] = mn;
         P.i0[blockIdx.x] = jn;
     }
 }
 
-__device__ __forceinline__ VI t_combine_argmin(const double *v, const int64_t *i, int64_t np, BlockRed &red)
+// entering decision from the per-strip pricing partials: the reference's first-negative rule or opt-in Dantzig
+__device__ __forceinline__ void combine_price(int64_t pricing, const Partials &P, int64_t np, BlockRed &red, double &mn,
+                                              int64_t &j)
 {
-    VI b{LPX_INF, LPX_NOIDX};
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x)
-        if (vi_less(v[k], i[k], b.v, b.i)) { b.v = v[k]; b.i = i[k]; }
-    return block_argmin(b, red);
-}
-__device__ __forceinline__ double t_combine_min(const double *v, int64_t np, BlockRed &red)
-{
-    double b = LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmin(b, v[k]);
-    return block_min(b, red);
-}
-__device__ __forceinline__ double t_combine_max(const double *v, int64_t np, BlockRed &red)
-{
-    double b = -LPX_INF;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = fmax(b, v[k]);
-    return block_max(b, red);
-}
-__device__ __forceinline__ int64_t t_combine_imin(const int64_t *i, int64_t np, BlockRed &red)
-{
-    int64_t b = LPX_NOIDX;
-    for (int64_t k = threadIdx.x; k < np; k += blockDim.x) b = i[k] < b ? i[k] : b;
-    return block_imin(b, red);
+    if (pricing == LPX_PRICE_DANTZIG) {
+        const VI t = combine_argmin(P.v0, P.i0, np, red);
+        mn = t.v;
+        j = t.i;
+    } else {
+        mn = combine_min(P.v0, np, red);
+        j = combine_imin(P.i0, np, red);
+    }
 }
 
 // ratio-test partial of one workgroup over rows [i] given the direction value di (all threads participate)
@@ -137,8 +136,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_column(lpx_tableau s, Partials 
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
     const bool f32 = ctrl->f32_phase != 0;
-    const double mn = t_combine_min(P.v0, nprice, red);
-    const int64_t j = t_combine_imin(P.i0, nprice, red);
+    double mn;
+    int64_t j;
+    combine_price(s.pricing, P, nprice, red, mn, j);
     const bool opt = lpx_is_optimal_min(mn);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctrl->counter += 1;
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_propose(lpx_tableau s, Partials
 {
     __shared__ BlockRed red;
     if (s.ctrl->status != LPX_RUNNING) return;
-    const double mn = t_combine_min(P.v0, nprice, red);
-    const int64_t j = t_combine_imin(P.i0, nprice, red);
+    double mn;
+    int64_t j;
+    combine_price(s.pricing, P, nprice, red, mn, j);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sendbuf[0] = mn;
         sendbuf[1] = (double)j; // exact: column indices < 2^53, LPX_NOIDX = 2^62
@@ -184,8 +185,12 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_select(lpx_tableau s, const dou
     for (int64_t g = 0; g < nranks; ++g) { // a handful of ranks: every thread scans them
         const double v = recv[g * msg];
         const int64_t idx = (int64_t)recv[g * msg + 1];
-        mn = fmin(mn, v);
-        if (idx < j) { j = idx; win = g; }
+        if (s.pricing == LPX_PRICE_DANTZIG) {
+            if (vi_less(v, idx, mn, j)) { mn = v; j = idx; win = g; }
+        } else {
+            mn = fmin(mn, v);
+            if (idx < j) { j = idx; win = g; }
+        }
     }
     const bool opt = lpx_is_optimal_min(mn);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_prepare(lpx_tableau s, Partials
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
-    const VI t = t_combine_argmin(R.v0, R.i0, nratio, red);
-    const double dmax = t_combine_max(R.v1, nratio, red);
+    const VI t = combine_argmin(R.v0, R.i0, nratio, red);
+    const double dmax = combine_max(R.v1, nratio, red);
     if (dmax <= 0.0) { // primal_solvers.py:144-147
         if (lead) {
             ctrl->aux_val = dmax;
@@ -282,27 +287,46 @@ __global__ __launch_bounds__(T_SMALL_THREADS) void k_t_pre_small(lpx_tableau s, 
     double mn = LPX_INF;
     int64_t j = LPX_NOIDX, win = 0;
     if (!PART) {
+        const bool dz = s.pricing == LPX_PRICE_DANTZIG;
         for (int64_t k = tid; k < nprice; k += nthr) {
-            mn = fmin(mn, P.v0[k]);
-            j = P.i0[k] < j ? P.i0[k] : j;
+            if (dz) {
+                if (vi_less(P.v0[k], P.i0[k], mn, j)) { mn = P.v0[k]; j = P.i0[k]; }
+            } else {
+                mn = fmin(mn, P.v0[k]);
+                j = P.i0[k] < j ? P.i0[k] : j;
+            }
         }
-        mn = wave_min(mn);
-        j = wave_imin(j);
+        if (dz) {
+            const VI t = wave_argmin(VI{mn, j});
+            mn = t.v;
+            j = t.i;
+        } else {
+            mn = wave_min(mn);
+            j = wave_imin(j);
+        }
         if (lane == 0) { red.a[wave] = mn; red.i[wave] = j; }
         __syncthreads();
         mn = red.a[0];
         j = red.i[0];
         for (int k = 1; k < nw; ++k) {
-            mn = fmin(mn, red.a[k]);
-            j = red.i[k] < j ? red.i[k] : j;
+            if (dz) {
+                if (vi_less(red.a[k], red.i[k], mn, j)) { mn = red.a[k]; j = red.i[k]; }
+            } else {
+                mn = fmin(mn, red.a[k]);
+                j = red.i[k] < j ? red.i[k] : j;
+            }
         }
         __syncthreads();
     } else {
         for (int64_t g = 0; g < nranks; ++g) {
             const double v = recv[g * msg];
             const int64_t idx = (int64_t)recv[g * msg + 1];
-            mn = fmin(mn, v);
-            if (idx < j) { j = idx; win = g; }
+            if (s.pricing == LPX_PRICE_DANTZIG) {
+                if (vi_less(v, idx, mn, j)) { mn = v; j = idx; win = g; }
+            } else {
+                mn = fmin(mn, v);
+                if (idx < j) { j = idx; win = g; }
+            }
         }
     }
     const bool opt = lpx_is_optimal_min(mn);
@@ -406,7 +430,7 @@ static void t_launch_update(const lpx_tableau *s, const TabWs &w, const Rank1Pla
     Rank1Args a{};
     a.M = s->T; a.rows = s->m + 1; a.cols = s->n + 1; a.ld = s->ld; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
-    a.price_v0 = w.price.v0; a.price_i0 = w.price.i0;
+    a.price_v0 = w.price.v0; a.price_i0 = w.price.i0; a.pricing = (int)s->pricing;
     lpx_k1_begin(st);
     lpx_rank1_launch<true>(p, a, st);
     lpx_k1_end(st);
@@ -505,20 +529,6 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_scatter(lpx_tableau s, double *
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
     if (i < s.m) x[s.basis[i]] = s.T[i * s.ld + s.n];
 }
-__global__ __launch_bounds__(1024) void k_t_cost(const float *c, const double *x, int64_t n, double *cost)
-{
-    __shared__ double part[16];
-    double acc = 0.0;
-    for (int64_t j = threadIdx.x; j < n; j += 1024) acc = fma((double)c[j], x[j], acc);
-    acc = wave_sum<double>(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        *cost = t;
-    }
-}
 extern "C" int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream)
 {
     int rc = check_tableau(s);
@@ -527,7 +537,7 @@ extern "C" int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_t_fill, dim3((unsigned)lpx_cdiv(s->n_global, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, x, s->n_global);
     hipLaunchKernelGGL(k_t_scatter, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, x);
-    hipLaunchKernelGGL(k_t_cost, dim3(1), dim3(1024), 0, st, c_global, (const double *)x, s->n_global, cost);
+    hipLaunchKernelGGL(k_cost, dim3(1), dim3(1024), 0, st, c_global, (const double *)x, s->n_global, cost);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

@@ -61,7 +61,7 @@ class TableauEngine:
     FIRST_CHUNK = 16
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
-                 group=None):
+                 group=None, pricing="first_negative"):
         torch = torch_cuda()
         self.torch = torch
         self.lib = _lib.load()
@@ -84,6 +84,7 @@ class TableauEngine:
         self.host_ctrl = _lib.LpxCtrl()
         s = self.s = _lib.LpxTableau()
         s.m, s.n, s.ld, s.col0, s.n_global = self.m, self.n, self.ld, self.col0, self.n_global
+        s.pricing = {"first_negative": _lib.PRICE_FIRST_NEGATIVE, "dantzig": _lib.PRICE_DANTZIG}[pricing]
         s.T, s.basis, s.var_state, s.ctrl = T.data_ptr(), basis.data_ptr(), var_state.data_ptr(), self.ctrl.data_ptr()
         s.log = self.log.data_ptr() if self.log_cap > 0 else None
         s.log_cap = self.log_cap
@@ -188,7 +189,9 @@ class PrimalTableauSimplexSolver:
 
     _LOG_CAP = 0
 
-    def __init__(self, c, A, b, basis, group=None, columns=None, n_global=None):
+    def __init__(self, c, A, b, basis, group=None, columns=None, n_global=None, pricing="first_negative"):
+        """``pricing="dantzig"`` (most negative reduced cost) is an opt-in extension: the reference's standard-form
+        solvers only have the first-negative-index rule, which stays the default."""
         if columns is None:
             self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
             self.m, self.n = A32.shape
@@ -221,7 +224,7 @@ class PrimalTableauSimplexSolver:
         self.counter = None
         self.optimum = None
         self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
-                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group)
+                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group, pricing=pricing)
 
     @staticmethod
     def _slack_block_is_identity(A_cols, j0, j1, k):

@@ -570,6 +570,8 @@ typedef struct lpo_tableau {
     double *e;    /* m+1 */
     double *rowr; /* ld */
     int32_t threads; /* >1: OpenMP update */
+    int32_t pricing; /* 0: first negative reduced cost (the reference's rule); 1: Dantzig, most negative, first index
+                        on ties -- the build's opt-in extension, no counterpart in the reference */
 } lpo_tableau;
 
 int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
@@ -582,9 +584,16 @@ int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
         s->counter += 1;
         double mn;
         int64_t j;
-        if (lpo_first_negative(s->T + m * ld, s->var_state, n, &mn, &j)) { /* primal_solvers.py:135-142 */
+        const int opt = lpo_first_negative(s->T + m * ld, s->var_state, n, &mn, &j); /* primal_solvers.py:135-142 */
+        if (opt) {
             s->status = LPO_OPTIMAL;
             break;
+        }
+        if (s->pricing == 1) { /* opt-in Dantzig rule: same optimality test, entering = first argmin */
+            const double *rc = s->T + m * ld;
+            j = 0;
+            for (int64_t k = 1; k < n; ++k)
+                if (rc[k] < rc[j]) j = k;
         }
         for (int64_t i = 0; i <= m; ++i) s->d[i] = s->T[i * ld + j]; /* d = (B^-1 A)[:, j], d[m] = rc_j */
         for (int64_t i = 0; i < m; ++i) xcol[i] = s->T[i * ld + n];

@@ -54,7 +54,7 @@ class _Tableau(C.Structure):
         ("f32_phase", C.c_int32), ("status", C.c_int32),
         ("counter", C.c_int64), ("pivots", C.c_int64),
         ("log", _ip), ("log_cap", C.c_int64),
-        ("d", _dp), ("e", _dp), ("rowr", _dp), ("threads", C.c_int32),
+        ("d", _dp), ("e", _dp), ("rowr", _dp), ("threads", C.c_int32), ("pricing", C.c_int32),
     ]
 
 
@@ -382,7 +382,7 @@ class OraclePrimalDual:
 class OracleTableau:
     """Tableau-form restatement (lpo_tableau_solve): carries T = B^-1 A, x_B and the reduced-cost row."""
 
-    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True):
+    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0):
         self.c, A32, self.b = preprocess(c, A, b)
         self.m, self.n = A32.shape
         m, n = self.m, self.n
@@ -418,6 +418,7 @@ class OracleTableau:
         s.f32_phase, s.pivots = 1, 0
         s.log, s.log_cap = _p(self.log, _ip), log_cap
         s.d, s.e, s.rowr, s.threads = _p(self._d, _dp), _p(self._e, _dp), _p(self._rowr, _dp), threads
+        s.pricing = int(pricing)
 
     def solve(self, maxiters=100):
         status = lib().lpo_tableau_solve(C.byref(self.s), int(maxiters))

@@ -109,3 +109,24 @@ def test_batched_rejects_oversize():
     solver = BatchedPrimalSolver(*[np.stack([p[k] for p in probs]) for k in range(4)])
     with pytest.raises(LpxBackendError):
         solver.solve(10)
+
+
+@pytest.mark.parametrize("m,n,seed", [(16, 32, 0), (64, 128, 1), (200, 520, 2), (600, 1300, 3)])
+def test_tableau_dantzig_opt_in_matches_oracle(m, n, seed):
+    """Opt-in most-negative pricing: no counterpart in the reference (parity unpinned); checked bit-exactly against
+    the oracle's restatement of the same rule, and it must reach the same optimal cost as the default rule."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(m, n, seed)
+    s = logged(PrimalTableauSimplexSolver, 20000)(c, A, b, basis, pricing="dantzig")
+    res = s.solve(20000)
+    o = O.OracleTableau(c, A, b, basis, log_cap=20000, pricing=1).solve(20000)
+    assert res.optimum and o.status == O.OPTIMAL
+    assert s.pivot_log().tolist() == o.log.tolist()
+    assert np.array_equal(res.x, o.x)  # elementwise path: bit-identical; the cost is a reduction (tree order)
+    assert abs(res.cost - o.cost) <= 1e-13 * max(1.0, abs(o.cost))
+    if m <= 64:
+        ref = O.OracleTableau(c, A, b, basis).solve(100000)
+        assert abs(ref.cost - res.cost) <= 1e-9 * max(1.0, abs(ref.cost))
+        assert res.iters <= ref.iters
