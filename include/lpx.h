@@ -193,7 +193,9 @@ int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream);
  * sendbuf[0] = local min rc, sendbuf[1] = global index of the first owned column with rc<0 (or 2^62),
  * sendbuf[2 .. 2+m] = that column of T (m entries + its reduced cost).  Length lpx_tableau_msg_len(m). */
 int64_t lpx_tableau_msg_len(int64_t m);
-int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *stream);
+/* rescan != 0: scan the reduced-cost row first (first pivot after construction / after the caller touched T);
+ * rescan == 0: use the pricing partials that the previous pivot's update kernel left behind. */
+int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, int rescan, void *stream);
 /* Part 2, after an all-gather of the proposals (recvbuf = nranks consecutive messages): pick the global
  * entering column (lowest index), run the ratio test on the replicated x_B column, update the local slice. */
 int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);

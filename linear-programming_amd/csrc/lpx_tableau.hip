@@ -480,7 +480,7 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     return lpx_run_iterations(&key, sizeof key, iters, st, one);
 }
 
-extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *stream)
+extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, int rescan, void *stream)
 {
     int rc = check_tableau(s);
     if (rc) return rc;
@@ -490,7 +490,7 @@ extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, void *
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
     const int64_t nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
-    t_launch_price(s, w, plan, st);
+    if (rescan) t_launch_price(s, w, plan, st);
     hipLaunchKernelGGL(k_t_propose, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.price, (int64_t)plan.grid.x, sendbuf);
     LPX_LAUNCH_CHECK();
     return LPX_OK;

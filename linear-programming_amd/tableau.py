@@ -145,8 +145,10 @@ class TableauEngine:
             _lib.check(self.lib.lpx_tableau_iterate(C.byref(self.s), int(iters), st))
             return
         ex = self.exchange
-        for _ in range(int(iters)):
-            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))
+        for it in range(int(iters)):
+            # the update kernel of the previous pivot leaves the pricing partials behind; only the first pivot of a
+            # call rescans the reduced-cost row (the caller may have touched T in between)
+            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbuf.data_ptr(), int(it == 0), st))
             ex.all_gather()
             _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
 
