@@ -212,6 +212,7 @@ struct ColsumArgs {
     // column-sum launch over B^-1; each workgroup finishes the y_i of its own rows into LDS first
     const double *ypart;
     int64_t ynch, yld;
+    int lds_weights; // weights staged in dynamic LDS (rpc * 8 bytes)
 };
 
 template <typename AccT>
@@ -249,9 +250,13 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
     const int64_t col = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     const int64_t row0 = (int64_t)blockIdx.y * a.rpc;
     const int64_t row1 = (row0 + a.rpc < a.rows) ? row0 + a.rpc : a.rows;
-    const bool lds_w = a.wmode == W_YPART;
+    // weights of this workgroup's rows go to LDS first: fetching them inside the streaming loop would put one or
+    // two dependent global loads (basis[i] -> c[...]) on every row's critical path
+    const bool lds_w = a.lds_weights != 0;
     if (lds_w) {
-        for (int64_t i = row0 + threadIdx.x; i < row1; i += blockDim.x) wl[i - row0] = fin_sum<AccT>(a.ypart, a.ynch, a.yld, i);
+        const int64_t rr = (a.wmode == W_BINV_ROW) ? a.ctrl->leave_r : 0;
+        for (int64_t i = row0 + threadIdx.x; i < row1; i += blockDim.x)
+            wl[i - row0] = (a.wmode == W_YPART) ? fin_sum<AccT>(a.ypart, a.ynch, a.yld, i) : colsum_weight<AccT>(a, i, rr);
         __syncthreads();
     }
     if (col >= a.cols) return;
@@ -840,13 +845,18 @@ static int check_revised(const lpx_revised *s)
     return LPX_OK;
 }
 
+// dynamic LDS for the row-chunk weights, 0 if the chunk is too tall (then weights are read in the loop)
+static inline size_t colsum_lds_bytes(int64_t rpc) { return (rpc * 8 <= 48 * 1024) ? (size_t)rpc * 8 : 0; }
+
 static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
 {
     ColsumArgs a{};
     a.M = s->Binv; a.ld = s->ldB; a.rows = s->m; a.cols = s->m; a.rpc = w.py.rpc;
     a.wmode = W_CB; a.c = s->c; a.basis = s->basis;
     a.part = w.ypart; a.ldp = w.ldyp; a.ctrl = s->ctrl;
-    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), 0, st, a);
+    const size_t lds = colsum_lds_bytes(w.py.rpc);
+    a.lds_weights = lds != 0;
+    hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), lds, st, a);
 }
 static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
 {
@@ -855,7 +865,8 @@ static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode,
     a.wmode = wmode; a.wvec = w.y; a.Binv = s->Binv; a.ldB = s->ldB;
     a.part = part; a.ldp = w.ldzp; a.ctrl = s->ctrl;
     a.ypart = w.ypart; a.ynch = w.py.nch; a.yld = w.ldyp;
-    const size_t lds = (wmode == W_YPART) ? (size_t)w.pa.rpc * sizeof(double) : 0;
+    const size_t lds = colsum_lds_bytes(w.pa.rpc);
+    a.lds_weights = lds != 0;
     hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), lds, st, a);
 }
 static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, double *rc_out, hipStream_t st)
@@ -874,7 +885,7 @@ static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, doubl
 static void launch_pricing_sums(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
 {
     launch_colsum_B(s, w, st);
-    if ((size_t)w.pa.rpc * sizeof(double) <= 48 * 1024) {
+    if (colsum_lds_bytes(w.pa.rpc) != 0) {
         launch_colsum_A(s, w, W_YPART, w.zpart, st);
     } else { // very tall matrices: finish y in its own launch
         launch_fin(s, w, FIN_Y, nullptr, st);
