@@ -13,6 +13,26 @@
 // A as m x n fp32, and the small vectors.
 #include "lpx_device.hpp"
 
+// Diagnostic build only (tools/batch_stamps.hip defines LPX_BATCH_STAMPS): per-phase cycle sums of lane 0, written to
+// a buffer of their own; the product build compiles the hooks away.
+#ifdef LPX_BATCH_STAMPS
+__device__ unsigned long long g_batch_stamps[16];
+#define LPX_STAMP_DECL unsigned long long st_last = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LPX_STAMP(k)                                   \
+    {                                                  \
+        const unsigned long long now = clock64();      \
+        st_acc[k] += now - st_last;                    \
+        st_last = now;                                 \
+    }
+#define LPX_STAMP_FLUSH                                                             \
+    if (threadIdx.x == 0)                                                           \
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_batch_stamps[q], st_acc[q]);
+#else
+#define LPX_STAMP_DECL
+#define LPX_STAMP(k)
+#define LPX_STAMP_FLUSH
+#endif
+
 struct BatchArgs {
     int64_t batch, m, n;
     const float *A, *b, *c, *Binv0;
@@ -67,16 +87,23 @@ struct BatchRed {
     double v[LPX_WAVES], w[LPX_WAVES];
     int i[LPX_WAVES];
 };
+struct BatchVI {
+    double v;
+    int i;
+    int pad;
+};
+struct BatchVIW {
+    double v, w;
+    int i;
+    int pad;
+};
 // min of v and (independently) min of idx over the workgroup
 __device__ __forceinline__ void batch_min_imin(double &v, int &idx, BatchRed &red)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        v = fmin(v, ov);
-        idx = oi < idx ? oi : idx;
-    }
+    const BatchVI r = wave_allreduce(BatchVI{v, idx, 0}, [](BatchVI x, BatchVI y) {
+        return BatchVI{fmin(x.v, y.v), y.i < x.i ? y.i : x.i, 0};
+    });
+    v = r.v; idx = r.i;
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red.v[wv] = v; red.i[wv] = idx; }
     __syncthreads();
@@ -91,13 +118,11 @@ __device__ __forceinline__ void batch_min_imin(double &v, int &idx, BatchRed &re
 // lexicographic argmin of (v, idx) and (independently) max of w over the workgroup
 __device__ __forceinline__ void batch_argmin_max(double &v, int &idx, double &w, BatchRed &red)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off), ow = __shfl_xor(w, off);
-        const int oi = __shfl_xor(idx, off);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        w = fmax(w, ow);
-    }
+    const BatchVIW r = wave_allreduce(BatchVIW{v, w, idx, 0}, [](BatchVIW x, BatchVIW y) {
+        const bool take = y.v < x.v || (y.v == x.v && y.i < x.i);
+        return BatchVIW{take ? y.v : x.v, fmax(x.w, y.w), take ? y.i : x.i, 0};
+    });
+    v = r.v; idx = r.i; w = r.w;
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red.v[wv] = v; red.i[wv] = idx; red.w[wv] = w; }
     __syncthreads();
@@ -171,13 +196,17 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
     bool f32 = true;
     int status = LPX_RUNNING;
     int64_t counter = 0, pivots = 0;
+    LPX_STAMP_DECL
     while (counter < a.maxiters) { // primal_solvers.py:191
         counter += 1;
+        LPX_STAMP(7)
         // ---- y_t = (c_B @ B^-1)_t (:64, first product): one lane per column, i ascending
         if (t < m)
             L.y[t] = f32 ? (double)batch_dot<float>(L.cb, 1, L.Binv + t, ldb, m)
                          : (double)batch_dot<double>(L.cb, 1, L.Binv + t, ldb, m);
+        LPX_STAMP(0)
         __syncthreads();
+        LPX_STAMP(1)
         // ---- rc_t = c_t - (y @ A)_t ; rc[basis] = 0 (:64-65); min and first negative (:135-142)
         double mn = LPX_INF;
         int j = 0x7FFFFFFF;
@@ -188,7 +217,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
             mn = rc;
             if (rc < 0.0) j = t;
         }
+        LPX_STAMP(2)
         batch_min_imin(mn, j, red);
+        LPX_STAMP(3)
         if (lpx_is_optimal_min(mn)) { // :140-142
             status = LPX_OPTIMAL;
             break;
@@ -204,7 +235,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
             r = t;
             dmax = di;
         }
+        LPX_STAMP(4)
         batch_argmin_max(th, r, dmax, red); // np.argmin: first minimum (:166)
+        LPX_STAMP(5)
         if (dmax <= 0.0) {                  // :144-147
             status = LPX_PRIMAL_UNBOUNDED;
             break;
@@ -217,8 +250,20 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
             L.rowr[t] = L.Binv[r * ldb + t];
         }
         __syncthreads();
+        LPX_STAMP(6)
         // ---- B^-1 <- E @ B^-1 ; bfs <- E @ bfs (:247-253) as a rank-1 update
-        {
+        if (LPX_BLOCK % m == 0) {
+            // lane owns column k and every (256/m)-th row: pivot-row entry in a register, 8 independent
+            // read-modify-writes in flight
+            const int rpp = LPX_BLOCK / m, k = t % m;
+            const double pr = L.rowr[k];
+#pragma unroll 8
+            for (int i = t / m; i < m; i += rpp) {
+                const double ei = L.e[i];
+                double *p = &L.Binv[i * ldb + k];
+                *p = (i == r) ? ei * pr : fma(ei, pr, *p);
+            }
+        } else {
             int i = t / m, k = t - i * m;
             const int dstep = LPX_BLOCK / m, kstep = LPX_BLOCK - dstep * m;
             for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
@@ -246,6 +291,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
         __syncthreads();
     }
 
+    LPX_STAMP_FLUSH
     // ---- result: x = scatter(x_B), cost = dot(c, x) in index order (primal_solvers.py:72-79)
     __syncthreads();
     for (int idx = t; idx < n; idx += LPX_BLOCK) L.rc[idx] = 0.0;

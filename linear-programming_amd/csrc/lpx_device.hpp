@@ -62,43 +62,87 @@ struct VI {
 // lexicographic "smaller value, then smaller index"
 __device__ __forceinline__ bool vi_less(double v, int64_t i, double bv, int64_t bi) { return v < bv || (v == bv && i < bi); }
 
+// Wave-level all-reduce on the VALU: DPP lane moves inside a row of 16 lanes (quad_perm xor 1, xor 2, row_ror 4,
+// row_ror 8) and gfx950's v_permlane16_swap / v_permlane32_swap across rows, instead of six rounds of ds_bpermute
+// shuffles through the LDS crossbar (~6x the latency; these reductions sit on the critical path of every small
+// kernel of the loop).  Every lane ends with the result; each input is combined exactly once.
+#define LPX_DPP_QUAD_XOR1 0xB1 /* quad_perm:[1,0,3,2] */
+#define LPX_DPP_QUAD_XOR2 0x4E /* quad_perm:[2,3,0,1] */
+#define LPX_DPP_ROW_ROR4 0x124
+#define LPX_DPP_ROW_ROR8 0x128
+
+template <typename T>
+struct LpxWords {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    int w[sizeof(T) / 4];
+};
+template <typename T, int CTRL>
+__device__ __forceinline__ T lpx_dpp_move(T v)
+{
+    LpxWords<T> u;
+    __builtin_memcpy(&u, &v, sizeof(T));
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = __builtin_amdgcn_update_dpp(u.w[k], u.w[k], CTRL, 0xf, 0xf, false);
+    T r;
+    __builtin_memcpy(&r, &u, sizeof(T));
+    return r;
+}
+// a = rows (v0, v0, v2, v2), b = rows (v1, v1, v3, v3) for SWAP32 == false (16-lane rows);
+// a = (lo half, lo half), b = (hi half, hi half) for SWAP32 == true
+template <typename T, bool SWAP32>
+__device__ __forceinline__ void lpx_lane_swap(T v, T &a, T &b)
+{
+    LpxWords<T> u, ua, ub;
+    __builtin_memcpy(&u, &v, sizeof(T));
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) {
+        if (SWAP32) {
+            const auto r = __builtin_amdgcn_permlane32_swap((unsigned)u.w[k], (unsigned)u.w[k], false, false);
+            ua.w[k] = (int)r[0];
+            ub.w[k] = (int)r[1];
+        } else {
+            const auto r = __builtin_amdgcn_permlane16_swap((unsigned)u.w[k], (unsigned)u.w[k], false, false);
+            ua.w[k] = (int)r[0];
+            ub.w[k] = (int)r[1];
+        }
+    }
+    __builtin_memcpy(&a, &ua, sizeof(T));
+    __builtin_memcpy(&b, &ub, sizeof(T));
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_allreduce(T v, Op op)
+{
+    v = op(v, lpx_dpp_move<T, LPX_DPP_QUAD_XOR1>(v));
+    v = op(v, lpx_dpp_move<T, LPX_DPP_QUAD_XOR2>(v));
+    v = op(v, lpx_dpp_move<T, LPX_DPP_ROW_ROR4>(v));
+    v = op(v, lpx_dpp_move<T, LPX_DPP_ROW_ROR8>(v));
+    T a, b;
+    lpx_lane_swap<T, false>(v, a, b);
+    v = op(a, b);
+    lpx_lane_swap<T, true>(v, a, b);
+    return op(a, b);
+}
+
 __device__ __forceinline__ VI wave_argmin(VI a)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(a.v, off);
-        const int64_t oi = __shfl_xor(a.i, off);
-        if (vi_less(ov, oi, a.v, a.i)) { a.v = ov; a.i = oi; }
-    }
-    return a;
+    return wave_allreduce(a, [](VI x, VI y) { return vi_less(y.v, y.i, x.v, x.i) ? y : x; });
 }
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+    return wave_allreduce(v, [](double x, double y) { return fmin(x, y); });
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    return wave_allreduce(v, [](double x, double y) { return fmax(x, y); });
 }
 __device__ __forceinline__ int64_t wave_imin(int64_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int64_t o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
+    return wave_allreduce(v, [](int64_t x, int64_t y) { return y < x ? y : x; });
 }
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    return wave_allreduce(v, [](T x, T y) { return x + y; });
 }
 
 // LDS scratch for block-level reductions (one per kernel)
