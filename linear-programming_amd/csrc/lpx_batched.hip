@@ -24,9 +24,12 @@ __device__ unsigned long long g_batch_stamps[16];
         st_acc[k] += now - st_last;                    \
         st_last = now;                                 \
     }
-#define LPX_STAMP_FLUSH                                                             \
-    if (threadIdx.x == 0)                                                           \
-        for (int q = 0; q < 8; ++q) atomicAdd(&g_batch_stamps[q], st_acc[q]);
+#define LPX_STAMP_FLUSH                                                                      \
+    if (threadIdx.x == 0) {                                                                  \
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_batch_stamps[q], st_acc[q]);                \
+        atomicAdd(&g_batch_stamps[8 + (__builtin_amdgcn_s_getreg(2308) & 3)], 1ULL);         \
+        atomicAdd(&g_batch_stamps[12 + (__builtin_amdgcn_s_getreg(6148) & 3)], 1ULL);        \
+    }
 #else
 #define LPX_STAMP_DECL
 #define LPX_STAMP(k)
@@ -311,77 +314,115 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Shape-specialised kernel for m in {8, 16, 32, 64}, n <= 256.
+// One wave per LP: m <= 64 (a multiple of 8), n <= 256.
 //
-// Same arithmetic in the same order as k_batched_primal (bit-identical results), laid out for the critical path,
-// which is three chains of m dependent fmas per pivot (y, rc, d):
-//  * m is a template parameter: the chains are straight-line code, every LDS address an immediate, so a step
-//    costs one fma plus ~one load instead of a dozen address/convert/move instructions;
-//  * lane t keeps column t of A in registers for the whole solve (A is read from HBM once, coalesced, and never
-//    again; the rc chain reads only y from LDS); LDS holds B^-1 and a few vectors, ~37 KB at m = 64, so four
-//    workgroups share a CU and their chains interleave;
-//  * each wave publishes the column of its own first negative reduced cost next to its partial minimum, which
-//    folds "broadcast the entering column" into the barrier of the pricing reduction;
-//  * direction, ratio test, eta column and x_B live in wave 0 (m <= 64 rows): that reduction is pure DPP, no barrier;
-//  * four barriers per pivot.
-template <int M>
-struct __attribute__((aligned(16))) FixedLds {
-    static constexpr int LDB = M + 1; // row pad: column reads hit distinct banks
-    double Binv[M * LDB];
-    double y[M], e[M], rowr[M], cbd[M]; // cbd[i] = c[basis[i]]
-    double xs[LPX_BLOCK];
-    float cf[LPX_BLOCK];
-    float acol[LPX_WAVES][M]; // candidate entering columns, one slot per wave
-    double red_mn[LPX_WAVES];
-    int red_j[LPX_WAVES];
-    int vst[LPX_BLOCK];
-    int r, leave, stat, pad;
+// Same arithmetic in the same order as k_batched_primal (bit-identical results).  What bounds a pivot at these
+// sizes is not bandwidth but the latency of three chains of m dependent fmas (y, rc, d) and the instruction
+// issue of a lone wave (tools/ubench.hip: ~6.5 cycles per fp64 fma, ~13.5 per LDS instruction of any width, 60
+// cycles LDS latency).  With a 256-lane workgroup per LP three of four waves idle through every chain, so here an
+// LP owns ONE wave and the four SIMDs of a CU run four LPs; nothing ever waits on another wave:
+//  * lane t is row t of B^-1 and of x_B, and column t (t+64, ...) of A;
+//  * A lives in registers for the whole solve (read from HBM once, coalesced): the rc chains read only y, as one
+//    broadcast ds_read_b128 per two steps shared by all columns of the lane; the entering column reaches the d chain
+//    through v_readlane, not through memory;
+//  * B^-1 is the only matrix in LDS (rows of 66 doubles: 16-byte aligned rows for b128 row access, conflict-free
+//    column access): 4 LPs per CU at m = 64, more for smaller m;
+//  * min(rc) and max(d) are only ever compared with a threshold and the entering/leaving indices are "first lane
+//    that ...": ballots, plus one 64-bit min on DPP for the ratio test;
+//  * the pivot row of E @ B^-1 is e_r * row_r, not row_r + e_r * row_r: lane r takes its addend from a row of
+//    -0.0 (fma(a, b, -0.0) == a * b bit for bit), so the update is one select-free fma stream over b128 accesses.
+#define LPX_WAVE_LDB 66
+
+struct WaveLds {
+    double *Binv; // m x 66
+    double *y, *cbd, *negz, *xs;
+    float *cf;
+    int *vst;
+    int64_t bytes;
 };
-
-template <int M>
-__global__ __launch_bounds__(LPX_BLOCK) void k_batched_fixed(BatchArgs a)
+__host__ __device__ static inline WaveLds wave_lds(int64_t m, int64_t cpl, char *base)
 {
-    constexpr int LDB = M + 1;
-    constexpr int ACTIVE = M * M < LPX_BLOCK ? M * M : LPX_BLOCK; // lanes of the rank-1 update
-    constexpr int RPP = ACTIVE / M;                                // rows covered per pass
-    constexpr int CNT = M / RPP;                                   // B^-1 entries per lane
-    static_assert(M % 4 == 0 && M <= 64 && LPX_BLOCK % M == 0, "m must divide the workgroup and fit one wave");
-    __shared__ FixedLds<M> S;
-    const int n = (int)a.n, t = threadIdx.x, wv = t >> 6;
-    const int64_t lp = blockIdx.x;
-    const bool has_col = t < n, has_row = t < M;
+    WaveLds L;
+    char *p = base;
+    auto take = [&](int64_t bytes) {
+        char *q = p;
+        p += (bytes + 15) / 16 * 16;
+        return q;
+    };
+    L.Binv = (double *)take(8 * m * LPX_WAVE_LDB);
+    L.y = (double *)take(8 * 64);
+    L.cbd = (double *)take(8 * 64);
+    L.negz = (double *)take(8 * 64);
+    L.xs = (double *)take(8 * 64 * cpl);
+    L.cf = (float *)take(4 * 64 * cpl);
+    L.vst = (int *)take(4 * 64 * cpl);
+    L.bytes = (int64_t)(p - base);
+    return L;
+}
 
-    // ---- column t of A and c_t into registers; B^-1, basis, c_B into LDS
-    float Ac[M];
-    float ct = 0.f;
-    {
-        const float *gA = a.A + lp * (int64_t)M * n;
+// v of lane `lane` (wave-uniform) through the scalar unit
+template <typename T>
+__device__ __forceinline__ T lane_bcast(T v, int lane)
+{
+    LpxWords<T> u;
+    __builtin_memcpy(&u, &v, sizeof(T));
 #pragma unroll
-        for (int k = 0; k < M; ++k) Ac[k] = has_col ? gA[(int64_t)k * n + t] : 0.f;
-        if (has_col) ct = a.c[lp * n + t];
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = __builtin_amdgcn_readlane(u.w[k], lane);
+    T r;
+    __builtin_memcpy(&r, &u, sizeof(T));
+    return r;
+}
+
+// CPL columns of A per lane, held as ColT (double: no conversion inside the rc chain; float when 4 columns per lane
+// would not fit the register file as doubles)
+template <int CPL, typename ColT>
+__global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
+{
+    constexpr int LDB = LPX_WAVE_LDB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = (int)a.m, n = (int)a.n, t = threadIdx.x;
+    const int64_t lp = blockIdx.x;
+    const WaveLds S = wave_lds(m, CPL, smem);
+    const bool has_row = t < m;
+    const int trow = has_row ? t : 0; // idle lanes shadow row 0 so that every address stays in range
+
+    // ---- columns t, t+64, ... of A and their costs into registers
+    ColT Ac[CPL][64];
+    float ct[CPL];
+    {
+        const float *gA = a.A + lp * (int64_t)m * n;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int col = t + 64 * q, cc = col < n ? col : n - 1;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) Ac[q][k] = (ColT)gA[(int64_t)(k < m ? k : m - 1) * n + cc];
+            ct[q] = a.c[lp * n + cc];
+            S.cf[col] = col < n ? ct[q] : 0.f;
+            S.vst[col] = 0;
+        }
     }
-    S.cf[t] = ct;
-    S.vst[t] = 0;
-    for (int idx = t; idx < M * M; idx += LPX_BLOCK) {
-        const int i = idx / M, k = idx % M;
-        S.Binv[i * LDB + k] = a.Binv0 ? (double)a.Binv0[lp * (int64_t)M * M + idx] : (i == k ? 1.0 : 0.0);
-    }
+    // ---- B^-1, basis, c_B, x_B = B^-1 b in float32 (primal_solvers.py:38)
+    for (int i = 0; i < m; ++i)
+        if (has_row) S.Binv[i * LDB + t] = a.Binv0 ? (double)a.Binv0[lp * (int64_t)m * m + (int64_t)i * m + t] : (i == t ? 1.0 : 0.0);
+    S.negz[t] = -0.0;
     int bas = 0;
-    if (has_row) bas = (int)a.basis[lp * M + t];
-    if (t == 0) S.stat = LPX_RUNNING;
+    if (has_row) {
+        bas = (int)a.basis[lp * m + t];
+        S.y[t] = (double)a.b[lp * m + t];
+    }
     __syncthreads();
     double xB = 0.0;
     if (has_row) {
         S.vst[bas] = 1;
         S.cbd[t] = (double)S.cf[bas];
-        // bfs = inv_basis_matrix @ b in float32 (primal_solvers.py:38)
         float s0 = 0.f;
-#pragma unroll
-        for (int k = 0; k < M; ++k) s0 = fmaf((float)S.Binv[t * LDB + k], a.b[lp * M + k], s0);
+        for (int k = 0; k < m; ++k) s0 = fmaf((float)S.Binv[t * LDB + k], (float)S.y[k], s0);
         xB = (double)s0;
     }
     __syncthreads();
-    bool basic = S.vst[t] != 0;
+    bool basic[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) basic[q] = S.vst[t + 64 * q] != 0;
 
     int status = LPX_RUNNING;
     int64_t counter = 0, pivots = 0;
@@ -391,122 +432,142 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_fixed(BatchArgs a)
     auto iterate = [&](auto tag) -> bool {
         using AccT = decltype(tag);
         constexpr bool F32 = sizeof(AccT) == 4;
-        LPX_STAMP(7)
-        // ---- y_t = (c_B @ B^-1)_t (:64, first product): lane t of wave 0, i ascending
-        if (has_row) {
-            AccT acc = (AccT)0;
+        if constexpr (sizeof(ColT) == 4) { // keep the float -> double conversions inside the chain (registers)
 #pragma unroll
-            for (int i = 0; i < M; ++i) acc = fma((AccT)S.cbd[i], (AccT)S.Binv[i * LDB + t], acc);
-            S.y[t] = (double)acc;
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(Ac[q][k]));
+        }
+        LPX_STAMP(7)
+        // ---- y_t = (c_B @ B^-1)_t (:64, first product): column t, i ascending
+        {
+            AccT acc = (AccT)0;
+            const double *col = S.Binv + trow;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb * 8 < m) {
+#pragma unroll
+                    for (int i = kb * 8; i < kb * 8 + 8; ++i) acc = fma((AccT)S.cbd[i], (AccT)col[i * LDB], acc);
+                }
+            }
+            if (has_row) S.y[t] = (double)acc;
         }
         LPX_STAMP(0)
         __syncthreads();
         LPX_STAMP(1)
-        // ---- rc_t = c_t - (y @ A)_t ; rc[basis] = 0 (:64-65); min and first negative (:135-142)
-        double mn = LPX_INF;
+        // ---- rc = c - y @ A ; rc[basis] = 0 (:64-65).  min(rc) is only used as "min >= 0 or |min| <= atol"
+        //      (:140-142), i.e. no rc below -atol, and the entering index is the first rc < 0 (:135-139): ballots.
         int j = 0x7FFFFFFF;
-        if (has_col) {
-            AccT acc = (AccT)0;
-#pragma unroll
-            for (int k = 0; k < M; ++k) acc = fma((AccT)S.y[k], (AccT)Ac[k], acc);
-            double rc;
-            if constexpr (F32) rc = (double)(ct - acc);
-            else rc = (double)ct - acc;
-            if (basic) rc = 0.0;
-            mn = rc;
-            if (rc < 0.0) j = t;
-        }
-        LPX_STAMP(2)
+        bool open = false;
         {
-            const BatchVI w = wave_allreduce(BatchVI{mn, j, 0}, [](BatchVI x, BatchVI y) {
-                return BatchVI{fmin(x.v, y.v), y.i < x.i ? y.i : x.i, 0};
-            });
-            if (w.i == t) { // this wave's candidate for the entering column
+            AccT acc[CPL];
 #pragma unroll
-                for (int k = 0; k < M; k += 4) *(f4_t *)&S.acol[wv][k] = f4_t{Ac[k], Ac[k + 1], Ac[k + 2], Ac[k + 3]};
-            }
-            if ((t & 63) == 0) { S.red_mn[wv] = w.v; S.red_j[wv] = w.i; }
-        }
-        __syncthreads();
-        mn = S.red_mn[0]; j = S.red_j[0];
+            for (int q = 0; q < CPL; ++q) acc[q] = (AccT)0;
 #pragma unroll
-        for (int k = 1; k < LPX_WAVES; ++k) {
-            mn = fmin(mn, S.red_mn[k]);
-            j = S.red_j[k] < j ? S.red_j[k] : j;
-        }
-        LPX_STAMP(3)
-        if (lpx_is_optimal_min(mn)) { // :140-142
-            status = LPX_OPTIMAL;
-            return false;
-        }
-        // ---- wave 0: d_t = (B^-1 @ A[:, j])_t (:129), ratios (:165), max(d) (:146), eta column (:236-244),
-        //      copy of the old pivot row, bfs <- E @ bfs
-        if (wv == 0) {
-            double di = -LPX_INF, th = LPX_INF;
-            int r = 0x7FFFFFFF;
-            if (has_row) {
-                const float *col = S.acol[(j >> 6) & (LPX_WAVES - 1)];
-                AccT acc = (AccT)0;
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb * 8 < m) {
 #pragma unroll
-                for (int k = 0; k < M; ++k) acc = fma((AccT)S.Binv[t * LDB + k], (AccT)col[k], acc);
-                di = (double)acc;
-                th = lpx_psd(xB, di, F32);
-                r = t;
-            }
-            LPX_STAMP(4)
-            const BatchVIW w = wave_allreduce(BatchVIW{th, di, r, 0}, [](BatchVIW x, BatchVIW y) {
-                const bool take = y.v < x.v || (y.v == x.v && y.i < x.i); // np.argmin: first minimum (:166)
-                return BatchVIW{take ? y.v : x.v, fmax(x.w, y.w), take ? y.i : x.i, 0};
-            });
-            LPX_STAMP(5)
-            if (w.w <= 0.0) { // :144-147
-                if (t == 0) S.stat = LPX_PRIMAL_UNBOUNDED;
-            } else {
-                r = __builtin_amdgcn_readfirstlane(w.i);
-                const double dr = __shfl(di, r), xr = __shfl(xB, r);
-                if (has_row) {
-                    const double e = (t == r) ? 1.0 / dr : (-di) / dr;
-                    S.e[t] = e;
-                    S.rowr[t] = S.Binv[r * LDB + t];
-                    xB = (t == r) ? e * xr : fma(e, xr, xB);
-                    if (t == r) {
-                        if (a.log && pivots < a.log_cap) {
-                            int64_t *lg = a.log + (lp * a.log_cap + pivots) * 3;
-                            lg[0] = r; lg[1] = j; lg[2] = bas;
-                        }
-                        S.r = r;
-                        S.leave = bas;
-                        bas = j; // :261
+                    for (int k = kb * 8; k < kb * 8 + 8; ++k) {
+                        const AccT yk = (AccT)S.y[k];
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][k], acc[q]);
                     }
                 }
             }
+            LPX_STAMP(2)
+#pragma unroll
+            for (int q = CPL - 1; q >= 0; --q) {
+                double rc;
+                if constexpr (F32) rc = (double)(ct[q] - acc[q]);
+                else rc = (double)ct[q] - acc[q];
+                if (basic[q] || t + 64 * q >= n) rc = 0.0;
+                const unsigned long long neg = __ballot(rc < 0.0);
+                open = open || __ballot(rc < -LPX_ATOL) != 0;
+                if (neg) j = 64 * q + __builtin_ctzll(neg);
+            }
         }
-        __syncthreads();
-        LPX_STAMP(6)
-        if (S.stat != LPX_RUNNING) {
-            status = S.stat;
+        LPX_STAMP(3)
+        if (!open) { // :140-142
+            status = LPX_OPTIMAL;
             return false;
         }
-        // ---- B^-1 <- E @ B^-1 (:247-253) as a rank-1 update: lane owns column k and every RPP-th row
-        const int r = S.r;
-        if (t == S.leave) basic = false;
-        if (t == j) {
-            basic = true;
-            S.cbd[r] = (double)ct;
-        }
-        if (t < ACTIVE) {
-            const int k = t % M, i0 = t / M;
-            const double pr = S.rowr[k];
-            double ei[CNT], bv[CNT];
+        j = j < n ? j : 0; // only reachable with NaNs in the data; keeps every index in range
+        // ---- d_t = (B^-1 @ A[:, j])_t (:129): row t, k ascending; A[k][j] comes from its owner lane by v_readlane
+        double di;
+        float cj = 0.f;
+        {
+            const int lj = j & 63, qj = j >> 6;
+            const double *row = S.Binv + trow * LDB;
+            AccT acc = (AccT)0;
 #pragma unroll
-            for (int q = 0; q < CNT; ++q) {
-                ei[q] = S.e[i0 + q * RPP];
-                bv[q] = S.Binv[(i0 + q * RPP) * LDB + k];
+            for (int q = 0; q < CPL; ++q) {
+                if (q == qj) {
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        if (kb * 8 < m) {
+#pragma unroll
+                            for (int k = kb * 8; k < kb * 8 + 8; ++k)
+                                acc = fma((AccT)row[k], (AccT)lane_bcast(Ac[q][k], lj), acc);
+                        }
+                    }
+                    cj = lane_bcast(ct[q], lj);
+                }
             }
+            di = has_row ? (double)acc : -LPX_INF;
+        }
+        // ---- ratios (:165), max(d) (:146), np.argmin (:166): the first lane holding the minimum ratio
+        const double th = has_row ? lpx_psd(xB, di, F32) : LPX_INF;
+        LPX_STAMP(4)
+        if (__ballot(di > 0.0) == 0) { // max(d) <= 0 (:144-147)
+            status = LPX_PRIMAL_UNBOUNDED;
+            return false;
+        }
+        const double thmin = wave_min(th);
+        const unsigned long long at = __ballot(th == thmin);
+        const int r = at ? __builtin_ctzll(at) : 0;
+        LPX_STAMP(5)
+        // ---- eta column (:236-244), bfs <- E @ bfs, bookkeeping (:261)
+        const double dr = lane_bcast(di, r), xr = lane_bcast(xB, r);
+        const int leaving = lane_bcast(bas, r);
+        const double e = ((t == r) ? 1.0 : -di) / dr;
+        xB = (t == r) ? e * xr : fma(e, xr, xB);
+        if (t == r) {
+            if (a.log && pivots < a.log_cap) {
+                int64_t *lg = a.log + (lp * a.log_cap + pivots) * 3;
+                lg[0] = r; lg[1] = j; lg[2] = leaving;
+            }
+            bas = j;
+            S.cbd[r] = (double)cj;
+        }
 #pragma unroll
-            for (int q = 0; q < CNT; ++q) bv[q] = (i0 + q * RPP == r) ? ei[q] * pr : fma(ei[q], pr, bv[q]);
+        for (int q = 0; q < CPL; ++q) {
+            if (t + 64 * q == leaving) basic[q] = false;
+            if (t + 64 * q == j) basic[q] = true;
+        }
+        LPX_STAMP(6)
+        // ---- B^-1 <- E @ B^-1 (:247-253): row t += e_t * row r; row r = e_r * row r (addend -0.0)
+        if (has_row) {
+            const d2_t *src = (const d2_t *)((t == r) ? S.negz : S.Binv + t * LDB);
+            d2_t *dst = (d2_t *)(S.Binv + t * LDB);
+            const d2_t *rowr = (const d2_t *)(S.Binv + r * LDB);
 #pragma unroll
-            for (int q = 0; q < CNT; ++q) S.Binv[(i0 + q * RPP) * LDB + k] = bv[q];
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb * 8 < m) {
+                    d2_t own[4], rr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        own[u] = src[kb * 4 + u];
+                        rr[u] = rowr[kb * 4 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        own[u].x = fma(e, rr[u].x, own[u].x);
+                        own[u].y = fma(e, rr[u].y, own[u].y);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dst[kb * 4 + u] = own[u];
+                }
+            }
         }
         pivots += 1;
         __syncthreads();
@@ -524,12 +585,16 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_fixed(BatchArgs a)
 
     LPX_STAMP_FLUSH
     // ---- result: x = scatter(x_B), cost = dot(c, x) in index order (primal_solvers.py:72-79)
-    S.xs[t] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) S.xs[t + 64 * q] = 0.0;
     __syncthreads();
     if (has_row) S.xs[bas] = xB;
     __syncthreads();
-    if (has_col) a.x[lp * n + t] = S.xs[t];
-    if (has_row) a.basis[lp * M + t] = bas;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q)
+        if (t + 64 * q < n) a.x[lp * n + t + 64 * q] = S.xs[t + 64 * q];
+    if (has_row) a.basis[lp * m + t] = bas;
     if (t == 0) {
         double s1 = 0.0;
         for (int jx = 0; jx < n; ++jx) s1 = fma((double)S.cf[jx], S.xs[jx], s1);
@@ -540,10 +605,19 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_fixed(BatchArgs a)
     }
 }
 
-template <int M>
-static void batched_fixed_launch(const BatchArgs &a, hipStream_t stream)
+template <int CPL, typename ColT>
+static int batched_wave_launch(const BatchArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_batched_fixed<M>, dim3((unsigned)a.batch), dim3(LPX_BLOCK), 0, stream, a);
+    int64_t bytes = wave_lds(a.m, CPL, nullptr).bytes;
+    if (const char *pad = getenv("LPX_BATCH_LDS_PAD")) bytes += atoi(pad); // diagnostics: fewer LPs per CU
+    static int64_t configured = 0;
+    if (bytes > configured) {
+        LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        configured = bytes;
+    }
+    hipLaunchKernelGGL((k_batched_wave<CPL, ColT>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
 }
 
 extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
@@ -560,19 +634,10 @@ extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, con
     }
     BatchArgs a{batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
     const char *generic = getenv("LPX_BATCH_GENERIC"); // diagnostics: force the shape-generic kernel
-    if (!(generic && generic[0] == '1')) {
-        bool done = true;
-        switch (m) {
-        case 8: batched_fixed_launch<8>(a, (hipStream_t)stream); break;
-        case 16: batched_fixed_launch<16>(a, (hipStream_t)stream); break;
-        case 32: batched_fixed_launch<32>(a, (hipStream_t)stream); break;
-        case 64: batched_fixed_launch<64>(a, (hipStream_t)stream); break;
-        default: done = false;
-        }
-        if (done) {
-            LPX_LAUNCH_CHECK();
-            return LPX_OK;
-        }
+    if (m <= 64 && m % 8 == 0 && !(generic && generic[0] == '1')) {
+        if (n <= 64) return batched_wave_launch<1, double>(a, (hipStream_t)stream);
+        if (n <= 128) return batched_wave_launch<2, double>(a, (hipStream_t)stream);
+        return batched_wave_launch<4, float>(a, (hipStream_t)stream);
     }
     const int64_t bytes = batch_lds(m, n, nullptr).bytes;
     if (bytes > 158 * 1024) {

@@ -46,6 +46,7 @@ int main()
         const char *names[8] = {"y dot", "barrier", "rc dot", "reduce(min,first-neg)", "d dot + ratio", "reduce(argmin,max)", "eta + barrier", "rank-1 update + bookkeeping"};
         printf("rc=%d  %.3f ms  pivots=%lld  cycles/pivot=%.0f\n", rc, ms, tp, tot / tp);
         for (int q = 0; q < 8; ++q) printf("  %-30s %6.1f %%  %8.0f cycles/pivot\n", names[q], 100.0 * st[q] / tot, (double)st[q] / tp);
+        printf("  wave-0 SIMD histogram: %llu %llu %llu %llu ; wave slot (low 2 bits): %llu %llu %llu %llu\n", st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
     }
     return 0;
 }
