@@ -373,6 +373,40 @@ __device__ __forceinline__ T lane_bcast(T v, int lane)
     return r;
 }
 
+// Chains and the update run over blocks of 8 steps.  Left alone the compiler issues each LDS load right before its
+// use and a step waits out the full LDS latency (~100 cycles with four waves on the LDS); here block b+1's operands
+// are loaded (ld) while block b is computed (cp), and fences keep the two stages apart in the schedule.
+#define LPX_STAGE_FENCE            \
+    asm volatile("" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+template <typename Buf, typename Load, typename Compute>
+__device__ __forceinline__ void staged_blocks(int m, Load ld, Compute cp)
+{
+    Buf b0, b1;
+    ld(0, b0); // m >= 8
+#pragma unroll
+    for (int kb = 0; kb < 8; kb += 2) {
+        if (kb * 8 < m) {
+            if ((kb + 1) * 8 < m) ld(kb + 1, b1);
+            LPX_STAGE_FENCE
+            cp(kb, b0);
+            LPX_STAGE_FENCE
+            if ((kb + 1) * 8 < m) {
+                if (kb + 2 < 8 && (kb + 2) * 8 < m) ld(kb + 2, b0);
+                LPX_STAGE_FENCE
+                cp(kb + 1, b1);
+                LPX_STAGE_FENCE
+            }
+        }
+    }
+}
+struct WaveBuf8x2 {
+    double a[8], b[8];
+};
+struct WaveBufRow {
+    d2_t own[4], rr[4];
+};
+
 // CPL columns of A per lane, held as ColT (double: no conversion inside the rc chain; float when 4 columns per lane
 // would not fit the register file as doubles)
 template <int CPL, typename ColT>
@@ -443,13 +477,19 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
         {
             AccT acc = (AccT)0;
             const double *col = S.Binv + trow;
+            staged_blocks<WaveBuf8x2>(
+                m,
+                [&](int kb, WaveBuf8x2 &B) {
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                if (kb * 8 < m) {
+                    for (int u = 0; u < 8; ++u) {
+                        B.a[u] = S.cbd[kb * 8 + u];
+                        B.b[u] = col[(kb * 8 + u) * LDB];
+                    }
+                },
+                [&](int, WaveBuf8x2 &B) {
 #pragma unroll
-                    for (int i = kb * 8; i < kb * 8 + 8; ++i) acc = fma((AccT)S.cbd[i], (AccT)col[i * LDB], acc);
-                }
-            }
+                    for (int u = 0; u < 8; ++u) acc = fma((AccT)B.a[u], (AccT)B.b[u], acc);
+                });
             if (has_row) S.y[t] = (double)acc;
         }
         LPX_STAMP(0)
@@ -463,17 +503,20 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
             AccT acc[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) acc[q] = (AccT)0;
+            staged_blocks<WaveBuf8x2>(
+                m,
+                [&](int kb, WaveBuf8x2 &B) {
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                if (kb * 8 < m) {
+                    for (int u = 0; u < 8; ++u) B.a[u] = S.y[kb * 8 + u];
+                },
+                [&](int kb, WaveBuf8x2 &B) {
 #pragma unroll
-                    for (int k = kb * 8; k < kb * 8 + 8; ++k) {
-                        const AccT yk = (AccT)S.y[k];
+                    for (int u = 0; u < 8; ++u) {
+                        const AccT yk = (AccT)B.a[u];
 #pragma unroll
-                        for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][k], acc[q]);
+                        for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][kb * 8 + u], acc[q]);
                     }
-                }
-            }
+                });
             LPX_STAMP(2)
 #pragma unroll
             for (int q = CPL - 1; q >= 0; --q) {
@@ -502,14 +545,17 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (q == qj) {
+                    staged_blocks<WaveBuf8x2>(
+                        m,
+                        [&](int kb, WaveBuf8x2 &B) {
 #pragma unroll
-                    for (int kb = 0; kb < 8; ++kb) {
-                        if (kb * 8 < m) {
+                            for (int u = 0; u < 8; ++u) B.a[u] = row[kb * 8 + u];
+                        },
+                        [&](int kb, WaveBuf8x2 &B) {
 #pragma unroll
-                            for (int k = kb * 8; k < kb * 8 + 8; ++k)
-                                acc = fma((AccT)row[k], (AccT)lane_bcast(Ac[q][k], lj), acc);
-                        }
-                    }
+                            for (int u = 0; u < 8; ++u)
+                                acc = fma((AccT)B.a[u], (AccT)lane_bcast(Ac[q][kb * 8 + u], lj), acc);
+                        });
                     cj = lane_bcast(ct[q], lj);
                 }
             }
@@ -550,24 +596,24 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
             const d2_t *src = (const d2_t *)((t == r) ? S.negz : S.Binv + t * LDB);
             d2_t *dst = (d2_t *)(S.Binv + t * LDB);
             const d2_t *rowr = (const d2_t *)(S.Binv + r * LDB);
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                if (kb * 8 < m) {
-                    d2_t own[4], rr[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        own[u] = src[kb * 4 + u];
-                        rr[u] = rowr[kb * 4 + u];
-                    }
+            staged_blocks<WaveBufRow>(
+                m,
+                [&](int kb, WaveBufRow &B) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        own[u].x = fma(e, rr[u].x, own[u].x);
-                        own[u].y = fma(e, rr[u].y, own[u].y);
+                        B.own[u] = src[kb * 4 + u];
+                        B.rr[u] = rowr[kb * 4 + u];
+                    }
+                },
+                [&](int kb, WaveBufRow &B) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        B.own[u].x = fma(e, B.rr[u].x, B.own[u].x);
+                        B.own[u].y = fma(e, B.rr[u].y, B.own[u].y);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) dst[kb * 4 + u] = own[u];
-                }
-            }
+                    for (int u = 0; u < 4; ++u) dst[kb * 4 + u] = B.own[u];
+                });
         }
         pivots += 1;
         __syncthreads();
