@@ -203,8 +203,12 @@ int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nran
 int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
 
 /* ------------------------------------------------------------------------------------ batched small LPs */
-/* One workgroup per LP, state resident in LDS (PrimalRevisedSimplexSolver semantics, slack or general start
- * basis with B^-1 supplied).  Arrays are batch-major.  Limits: m <= 64, n <= 128 (LPX_E_SIZE otherwise). */
+/* PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) (primal_solvers.py:176-263) for `batch` independent
+ * LPs of one shape, slack or general start basis (Binv0 = B^-1 per LP, or NULL for the identity).  Arrays are
+ * batch-major.  m <= 64, n <= 256: one wave per LP (A in registers, B^-1 in LDS, four LPs per CU at m = 64);
+ * larger shapes up to m, n <= 256 and 158 KB of LDS: one 256-lane workgroup per LP; beyond that LPX_E_SIZE.
+ * Both kernels accumulate every dot product in index order with fma and return identical bits.
+ * Environment: LPX_BATCH_KERNEL = wave | generic pins the kernel (tests). */
 int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                              const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
                              int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,

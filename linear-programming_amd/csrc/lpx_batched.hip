@@ -12,6 +12,8 @@
 // LDS image per LP:  B^-1 as m x (m+1) fp64 (row pad: column reads then hit distinct bank pairs),
 // A as m x n fp32, and the small vectors.
 #include "lpx_device.hpp"
+#include <stdlib.h>
+#include <string.h>
 
 // Diagnostic build only (tools/batch_stamps.hip defines LPX_BATCH_STAMPS): per-phase cycle sums of lane 0, written to
 // a buffer of their own; the product build compiles the hooks away.
@@ -379,22 +381,25 @@ __device__ __forceinline__ T lane_bcast(T v, int lane)
 #define LPX_STAGE_FENCE            \
     asm volatile("" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0);
-template <typename Buf, typename Load, typename Compute>
+// ld / cp get (block, buffer, steps in the block): 8, or with PARTIAL the runtime count of the last block of an m
+// that is not a multiple of 8 (uniform guards; the PARTIAL = false instantiation carries none).
+template <typename Buf, bool PARTIAL, typename Load, typename Compute>
 __device__ __forceinline__ void staged_blocks(int m, Load ld, Compute cp)
 {
     Buf b0, b1;
-    ld(0, b0); // m >= 8
+    auto cnt = [&](int kb) { return PARTIAL ? (m - kb * 8 < 8 ? m - kb * 8 : 8) : 8; };
+    ld(0, b0, cnt(0));
 #pragma unroll
     for (int kb = 0; kb < 8; kb += 2) {
         if (kb * 8 < m) {
-            if ((kb + 1) * 8 < m) ld(kb + 1, b1);
+            if ((kb + 1) * 8 < m) ld(kb + 1, b1, cnt(kb + 1));
             LPX_STAGE_FENCE
-            cp(kb, b0);
+            cp(kb, b0, cnt(kb));
             LPX_STAGE_FENCE
             if ((kb + 1) * 8 < m) {
-                if (kb + 2 < 8 && (kb + 2) * 8 < m) ld(kb + 2, b0);
+                if (kb + 2 < 8 && (kb + 2) * 8 < m) ld(kb + 2, b0, cnt(kb + 2));
                 LPX_STAGE_FENCE
-                cp(kb + 1, b1);
+                cp(kb + 1, b1, cnt(kb + 1));
                 LPX_STAGE_FENCE
             }
         }
@@ -409,7 +414,7 @@ struct WaveBufRow {
 
 // CPL columns of A per lane, held as ColT (double: no conversion inside the rc chain; float when 4 columns per lane
 // would not fit the register file as doubles)
-template <int CPL, typename ColT>
+template <int CPL, typename ColT, bool PARTIAL>
 __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
 {
     constexpr int LDB = LPX_WAVE_LDB;
@@ -477,18 +482,19 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
         {
             AccT acc = (AccT)0;
             const double *col = S.Binv + trow;
-            staged_blocks<WaveBuf8x2>(
+            staged_blocks<WaveBuf8x2, PARTIAL>(
                 m,
-                [&](int kb, WaveBuf8x2 &B) {
+                [&](int kb, WaveBuf8x2 &B, int cnt) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         B.a[u] = S.cbd[kb * 8 + u];
-                        B.b[u] = col[(kb * 8 + u) * LDB];
+                        B.b[u] = col[(kb * 8 + (u < cnt ? u : 0)) * LDB]; // rows past m do not exist
                     }
                 },
-                [&](int, WaveBuf8x2 &B) {
+                [&](int, WaveBuf8x2 &B, int cnt) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc = fma((AccT)B.a[u], (AccT)B.b[u], acc);
+                    for (int u = 0; u < 8; ++u)
+                        if (u < cnt) acc = fma((AccT)B.a[u], (AccT)B.b[u], acc);
                 });
             if (has_row) S.y[t] = (double)acc;
         }
@@ -503,18 +509,20 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
             AccT acc[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) acc[q] = (AccT)0;
-            staged_blocks<WaveBuf8x2>(
+            staged_blocks<WaveBuf8x2, PARTIAL>(
                 m,
-                [&](int kb, WaveBuf8x2 &B) {
+                [&](int kb, WaveBuf8x2 &B, int) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) B.a[u] = S.y[kb * 8 + u];
                 },
-                [&](int kb, WaveBuf8x2 &B) {
+                [&](int kb, WaveBuf8x2 &B, int cnt) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const AccT yk = (AccT)B.a[u];
+                        if (u < cnt) {
+                            const AccT yk = (AccT)B.a[u];
 #pragma unroll
-                        for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][kb * 8 + u], acc[q]);
+                            for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][kb * 8 + u], acc[q]);
+                        }
                     }
                 });
             LPX_STAMP(2)
@@ -545,16 +553,16 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (q == qj) {
-                    staged_blocks<WaveBuf8x2>(
+                    staged_blocks<WaveBuf8x2, PARTIAL>(
                         m,
-                        [&](int kb, WaveBuf8x2 &B) {
+                        [&](int kb, WaveBuf8x2 &B, int) {
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) B.a[u] = row[kb * 8 + u];
+                            for (int u = 0; u < 8; ++u) B.a[u] = row[kb * 8 + u]; // rows are 66 doubles long
                         },
-                        [&](int kb, WaveBuf8x2 &B) {
+                        [&](int kb, WaveBuf8x2 &B, int cnt) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u)
-                                acc = fma((AccT)B.a[u], (AccT)lane_bcast(Ac[q][kb * 8 + u], lj), acc);
+                                if (u < cnt) acc = fma((AccT)B.a[u], (AccT)lane_bcast(Ac[q][kb * 8 + u], lj), acc);
                         });
                     cj = lane_bcast(ct[q], lj);
                 }
@@ -596,16 +604,16 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
             const d2_t *src = (const d2_t *)((t == r) ? S.negz : S.Binv + t * LDB);
             d2_t *dst = (d2_t *)(S.Binv + t * LDB);
             const d2_t *rowr = (const d2_t *)(S.Binv + r * LDB);
-            staged_blocks<WaveBufRow>(
+            staged_blocks<WaveBufRow, PARTIAL>( // whole blocks of 8 columns: the row pad absorbs the excess
                 m,
-                [&](int kb, WaveBufRow &B) {
+                [&](int kb, WaveBufRow &B, int) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         B.own[u] = src[kb * 4 + u];
                         B.rr[u] = rowr[kb * 4 + u];
                     }
                 },
-                [&](int kb, WaveBufRow &B) {
+                [&](int kb, WaveBufRow &B, int) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         B.own[u].x = fma(e, B.rr[u].x, B.own[u].x);
@@ -651,19 +659,24 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
     }
 }
 
+template <int CPL, typename ColT, bool PARTIAL>
+static int batched_wave_launch2(const BatchArgs &a, hipStream_t stream)
+{
+    const int64_t bytes = wave_lds(a.m, CPL, nullptr).bytes;
+    static int64_t configured = 0;
+    if (bytes > configured) {
+        LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT, PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+        configured = bytes;
+    }
+    hipLaunchKernelGGL((k_batched_wave<CPL, ColT, PARTIAL>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
 template <int CPL, typename ColT>
 static int batched_wave_launch(const BatchArgs &a, hipStream_t stream)
 {
-    int64_t bytes = wave_lds(a.m, CPL, nullptr).bytes;
-    if (const char *pad = getenv("LPX_BATCH_LDS_PAD")) bytes += atoi(pad); // diagnostics: fewer LPs per CU
-    static int64_t configured = 0;
-    if (bytes > configured) {
-        LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        configured = bytes;
-    }
-    hipLaunchKernelGGL((k_batched_wave<CPL, ColT>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
-    LPX_LAUNCH_CHECK();
-    return LPX_OK;
+    return a.m % 8 ? batched_wave_launch2<CPL, ColT, true>(a, stream) : batched_wave_launch2<CPL, ColT, false>(a, stream);
 }
 
 extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
@@ -679,8 +692,19 @@ extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, con
         return LPX_E_SIZE;
     }
     BatchArgs a{batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
-    const char *generic = getenv("LPX_BATCH_GENERIC"); // diagnostics: force the shape-generic kernel
-    if (m <= 64 && m % 8 == 0 && !(generic && generic[0] == '1')) {
+    // LPX_BATCH_KERNEL = wave | generic pins one of the two kernels (tests, diagnostics); both produce the same bits.
+    // Default: one wave per LP whenever the rows fit a wave.
+    const char *pin = getenv("LPX_BATCH_KERNEL");
+    const bool want_wave = pin && !strcmp(pin, "wave"), want_generic = pin && !strcmp(pin, "generic");
+    if (pin && pin[0] && !want_wave && !want_generic) {
+        lpx_set_error("lpx_batched_primal_solve: LPX_BATCH_KERNEL must be wave or generic, not '%s'", pin);
+        return LPX_E_ARG;
+    }
+    if (want_wave && m > 64) {
+        lpx_set_error("lpx_batched_primal_solve: the wave kernel takes m <= 64, not %lld", (long long)m);
+        return LPX_E_SIZE;
+    }
+    if (m <= 64 && !want_generic) {
         if (n <= 64) return batched_wave_launch<1, double>(a, (hipStream_t)stream);
         if (n <= 128) return batched_wave_launch<2, double>(a, (hipStream_t)stream);
         return batched_wave_launch<4, float>(a, (hipStream_t)stream);

@@ -100,6 +100,48 @@ def test_batched_other_shapes_and_limits(m, n):
         assert np.array_equal(res[i].x, o.x)
 
 
+@pytest.mark.parametrize("m,n", [(5, 12), (8, 16), (13, 40), (24, 64), (37, 100), (40, 128), (56, 200), (64, 256), (61, 129)])
+def test_batched_both_kernels_bit_identical(m, n, monkeypatch):
+    """The one-wave-per-LP kernel (whole and partial blocks of 8 rows; 1, 2 and 4 columns per lane) and the
+    shape-generic kernel return the same bits as each other and as the oracle, on full solves."""
+    from linprog_amd.batched import BatchedPrimalSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_primal(m, n, 100 + s) for s in range(5)]
+    out = {}
+    for kernel in ("wave", "generic"):
+        monkeypatch.setenv("LPX_BATCH_KERNEL", kernel)
+        solver = BatchedPrimalSolver(*[np.stack([p[k] for p in probs]) for k in range(4)], log_cap=2048)
+        res = solver.solve(100000)
+        out[kernel] = (res, solver.pivot_logs())
+    for i, p in enumerate(probs):
+        o = O.OracleRevised(*p, log_cap=2048).solve(100000)
+        for kernel in ("wave", "generic"):
+            res, logs = out[kernel]
+            assert logs[i].tolist() == o.log.tolist(), kernel
+            assert res[i].iters == o.iters and res[i].optimum == (o.status == O.OPTIMAL), kernel
+            assert np.array_equal(res[i].x, o.x) and res[i].cost == o.cost, kernel
+            assert res[i].basis.tolist() == o.basis.tolist(), kernel
+
+
+def test_batched_generic_kernel_above_one_wave(monkeypatch):
+    """m > 64 only fits the generic kernel; pinning the wave kernel there is an error, as is a bad pin."""
+    from linprog_amd.batched import BatchedPrimalSolver
+    from linprog_amd.exceptions import LpxBackendError
+    from oracle import oracle as O
+
+    probs = [gen.gen_primal(80, 170, s) for s in range(3)]
+    args = [np.stack([p[k] for p in probs]) for k in range(4)]
+    res = BatchedPrimalSolver(*args).solve(100000)
+    for i, p in enumerate(probs):
+        o = O.OracleRevised(*p).solve(100000)
+        assert res[i].iters == o.iters and np.array_equal(res[i].x, o.x) and res[i].cost == o.cost
+    for bad in ("wave", "nonsense"):
+        monkeypatch.setenv("LPX_BATCH_KERNEL", bad)
+        with pytest.raises(LpxBackendError):
+            BatchedPrimalSolver(*args).solve(10)
+
+
 def test_batched_rejects_oversize():
     from linprog_amd import _lib
     from linprog_amd.batched import BatchedPrimalSolver

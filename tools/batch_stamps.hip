@@ -2,6 +2,9 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Iinclude -Ilinear-programming_amd/csrc \
 //         tools/batch_stamps.hip -o tools/batch_stamps && ./tools/batch_stamps
 #define LPX_BATCH_STAMPS 1
+#ifdef ONE
+#define LPX_WAVE_ONE_PER_SIMD 1
+#endif
 #include <stdarg.h>
 #include <stdio.h>
 #include <vector>
