@@ -60,7 +60,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    # LPX_BENCH_FORCE_DIST=1: also build the process group at world size 1 (a one-GPU box can then run the RCCL
+    # collectives of the partitioned path with a single rank)
+    if world > 1 or os.environ.get("LPX_BENCH_FORCE_DIST"):
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -85,7 +92,7 @@ def main():
     t_setup = time.time() - t_setup
 
     def barrier():
-        if world > 1:
+        if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -94,7 +101,7 @@ def main():
     # K1 is timed with HIP events on the launch stream.  For the headline 20k x 40k workload they are recorded
     # inside the timed region.  The 1k x 2k workload is launch-bound and liblpx replays it as hipGraphs (event
     # records cannot ride along), so there K1 is timed in a separate eager pass of the same pivots afterwards.
-    events_in_timed = args.workload == "tableau" or world > 1
+    events_in_timed = args.workload == "tableau" or group is not None
     _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, torch.cuda.current_stream().cuda_stream))
     eng.enqueue(W)
     barrier()
@@ -111,7 +118,7 @@ def main():
         _lib.check(lib.lpx_profile_k1(1))
         eng.enqueue(extra)
         barrier()
-    if world > 1:
+    if group is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -170,7 +177,7 @@ def main():
         out["parity"] = None if chk is None else chk["parity"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 
@@ -274,7 +281,7 @@ def bench_batch(args, rank, world, group):
     basis0 = solver.basis.clone()
 
     def barrier():
-        if world > 1:
+        if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
