@@ -55,11 +55,15 @@ class BatchedPrimalSolver:
             self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(), self.pivots.data_ptr(),
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
 
+    def results(self):
+        """Raw batch-major outputs of the last launch on the host (one synchronising copy each)."""
+        return dict(x=self.x.cpu().numpy(), cost=self.cost.cpu().numpy(), basis=self.basis.cpu().numpy(),
+                    status=self.status.cpu().numpy(), iters=self.iters.cpu().numpy(), pivots=self.pivots.cpu().numpy())
+
     def solve(self, maxiters=100):
         self.enqueue(maxiters)
-        x, cost = self.x.cpu().numpy(), self.cost.cpu().numpy()
-        basis, status, iters = self.basis.cpu().numpy(), self.status.cpu().numpy(), self.iters.cpu().numpy()
-        self.raw = dict(x=x, cost=cost, basis=basis, status=status, iters=iters, pivots=self.pivots.cpu().numpy())
+        self.raw = self.results()
+        x, cost, basis, status, iters = (self.raw[k] for k in ("x", "cost", "basis", "status", "iters"))
         return [LinProgResult(x=x[i], basis=basis[i], cost=np.float64(cost[i]), iters=int(iters[i]),
                               optimum=bool(status[i] == _lib.OPTIMAL)) for i in range(self.B)]
 

@@ -636,4 +636,56 @@ double lpo_expand_and_cost(const double *xB, const int64_t *basis, const float *
     return acc;
 }
 
+/* A batch of independent LPs of one shape through lpo_primal_solve (PrimalRevisedSimplexSolver.solve,
+ * primal_solvers.py:176-263), one LP per OpenMP thread: the CPU side of SURVEY.md 8(d) config 3.  Slack or general
+ * start: Binv0 = float32 B^-1 per LP or NULL for the identity; x_B = B^-1 b in float32 (:38), accumulated in index
+ * order.  Outputs per LP: basis (in place), x (n), cost, status, iters (reference counter), pivots. */
+void lpo_primal_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                            const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                            int64_t *iters, int64_t *pivots, int64_t maxiters, int threads)
+{
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+    {
+        const int64_t mx = m > n ? m : n;
+        double *buf = (double *)malloc(sizeof(double) * (size_t)(m * m + 5 * m + 2 * n + mx));
+        int32_t *vs = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t l = 0; l < batch; ++l) {
+            lpo_revised s;
+            memset(&s, 0, sizeof s);
+            double *p = buf;
+            s.m = m; s.n = n;
+            s.A = A + l * m * n; s.b = b + l * m; s.c = c + l * n;
+            s.Binv = p; p += m * m;
+            s.xB = p; p += m;
+            s.y = p; p += m;
+            s.d = p; p += m;
+            s.e = p; p += m;
+            s.w = p; p += m;
+            s.rc = p; p += n;
+            s.row = p; p += n;
+            s.rowr = p;
+            s.basis = basis + l * m;
+            s.var_state = vs;
+            for (int64_t i = 0; i < m; ++i)
+                for (int64_t k = 0; k < m; ++k)
+                    s.Binv[i * m + k] = Binv0 ? (double)Binv0[(l * m + i) * m + k] : (i == k ? 1.0 : 0.0);
+            for (int64_t i = 0; i < m; ++i) {
+                float acc = 0.f;
+                for (int64_t k = 0; k < m; ++k) acc = fmaf((float)s.Binv[i * m + k], s.b[k], acc);
+                s.xB[i] = (double)acc;
+            }
+            for (int64_t j = 0; j < n; ++j) vs[j] = VS_LOWER;
+            for (int64_t i = 0; i < m; ++i) vs[s.basis[i]] = VS_BASIC;
+            s.f32_phase = 1;
+            status[l] = lpo_primal_solve(&s, maxiters);
+            iters[l] = s.counter;
+            pivots[l] = s.pivots;
+            cost[l] = lpo_expand_and_cost(s.xB, s.basis, s.c, m, n, x + l * n);
+        }
+        free(buf);
+        free(vs);
+    }
+}
+
 int lpo_version(void) { return 1; }

@@ -103,6 +103,9 @@ def lib():
         L.lpo_pd_theta.restype = None
         L.lpo_expand_and_cost.argtypes = [_dp, _ip, _fp, C.c_int64, C.c_int64, _dp]
         L.lpo_expand_and_cost.restype = C.c_double
+        L.lpo_primal_solve_batch.argtypes = [C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, _fp, _ip, _dp, _dp, _sp, _ip,
+                                             _ip, C.c_int64, C.c_int]
+        L.lpo_primal_solve_batch.restype = None
         _lib = L
     return _lib
 
@@ -195,6 +198,23 @@ def expand_and_cost(xB, basis, c32, n):
     x = np.empty(n)
     cost = lib().lpo_expand_and_cost(_p(xB, _dp), _p(basis, _ip), _p(c32, _fp), xB.size, n, _p(x, _dp))
     return x, cost
+
+
+def primal_solve_batch(c, A, b, basis, maxiters=100, threads=1):
+    """A batch of LPs of one shape (batch-major arrays, slack start: B = I) through lpo_primal_solve, one LP per
+    OpenMP thread.  Returns dict(x, basis, cost, status, iters, pivots)."""
+    A = np.ascontiguousarray(np.asarray(A).astype(np.float32))
+    b = np.ascontiguousarray(np.asarray(b).astype(np.float32))
+    c = np.ascontiguousarray(np.asarray(c).astype(np.float32))
+    basis = np.ascontiguousarray(np.array(basis).astype(np.int64))
+    B, m, n = A.shape
+    x, cost = np.empty((B, n)), np.empty(B)
+    status = np.empty(B, dtype=np.int32)
+    iters, pivots = np.empty(B, dtype=np.int64), np.empty(B, dtype=np.int64)
+    lib().lpo_primal_solve_batch(B, m, n, _p(A, _fp), _p(b, _fp), _p(c, _fp), None, _p(basis, _ip), _p(x, _dp),
+                                 _p(cost, _dp), _p(status, _sp), _p(iters, _ip), _p(pivots, _ip), int(maxiters),
+                                 int(threads))
+    return dict(x=x, basis=basis, cost=cost, status=status, iters=iters, pivots=pivots)
 
 
 # ------------------------------------------------------------------------------------------------ solvers
