@@ -202,6 +202,17 @@ int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nran
 /* x[n_global-sized on rank owning..] : x_B and basis are replicated, so every rank can expand: x, cost. */
 int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
 
+/* Dual simplex on the same tableau: DualNaiveSimplexSolver.solve with DualRevisedSimplexSolver's pivot
+ * (dual_solvers.py:47-120) -- leaving row = first x_B < 0 (:47-54), dual row = row r of T with basic columns forced
+ * to 0 (:38-39), ratio test (-rc_j)/row_j over row_j < 0, first argmin (:61-80), LPX_DUAL_UNBOUNDED when
+ * min(row) >= 0 (:41-44).  Same state struct, same K1; `pricing` is ignored. */
+int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, void *stream);
+/* Column-partitioned dual pivot.  Part 1: every rank picks the leaving row from its x_B replica and proposes its
+ * best owned column: sendbuf = [theta, global column, T[0..m, column]] (lpx_tableau_msg_len doubles). */
+int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, void *stream);
+/* Part 2, after an all-gather of the proposals: global first argmin of theta, update of the local slice. */
+int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);
+
 /* ------------------------------------------------------------------------------------ batched small LPs */
 /* PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) (primal_solvers.py:176-263) for `batch` independent
  * LPs of one shape, slack or general start basis (Binv0 = B^-1 per LP, or NULL for the identity).  Arrays are

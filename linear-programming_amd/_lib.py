@@ -80,6 +80,9 @@ _SIGS = {
     "lpx_tableau_msg_len": (i64, [i64]),
     "lpx_tableau_propose": (C.c_int, [C.POINTER(LpxTableau), vp, C.c_int, vp]),
     "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
+    "lpx_tableau_dual_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
+    "lpx_tableau_dual_propose": (C.c_int, [C.POINTER(LpxTableau), vp, vp]),
+    "lpx_tableau_dual_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
     "lpx_tableau_expand": (C.c_int, [C.POINTER(LpxTableau), vp, vp, vp, vp]),
     "lpx_batched_primal_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_pivot_update": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, vp]),

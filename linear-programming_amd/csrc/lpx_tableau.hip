@@ -518,6 +518,225 @@ extern "C" int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, i
     return LPX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Dual simplex on the same tableau (DualNaiveSimplexSolver.solve, dual_solvers.py:47-108): the leaving row is the
+// first x_B < 0 (x_B = column n, replicated when partitioned), the dual row is row r of T with basic columns
+// forced to 0 (:38-39), the reduced costs are row m, the ratio test (-rc_j)/row_j over row_j < 0 with first argmin
+// (:61-80).  The pivot itself is K1, unchanged.  Chain: k_td_row -> k_td_ratio -> k_td_prepare -> K1.
+// ---------------------------------------------------------------------------------------------------------
+
+// K5 (tableau): one partial (min x_B, first row with x_B < 0) per workgroup of rows
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_row(lpx_tableau s, Partials R)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const double v = (i < s.m) ? s.T[i * s.ld + s.n] : LPX_INF;
+    const double mn = block_min(v, red);
+    const int64_t first = block_imin((i < s.m && v < 0.0) ? i : LPX_NOIDX, red);
+    if (threadIdx.x == 0) {
+        R.v0[blockIdx.x] = mn;
+        R.i0[blockIdx.x] = first;
+    }
+}
+
+// K6 (tableau): leaving-row decision (every workgroup re-derives it from the row partials) + one partial
+// (min theta with first global column, min of the dual row) per column strip
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_ratio(lpx_tableau s, Partials R, int64_t nrow, Partials P, int64_t strip)
+{
+    __shared__ BlockRed red;
+    lpx_ctrl *ctrl = s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const bool f32 = ctrl->f32_phase != 0;
+    const double mn = combine_min(R.v0, nrow, red);
+    const int64_t r = combine_imin(R.i0, nrow, red);
+    const bool opt = lpx_is_optimal_min(mn); // dual_solvers.py:52-54
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->counter += 1;
+        ctrl->price_val = mn;
+        if (opt) ctrl->status = LPX_OPTIMAL;
+        else ctrl->leave_r = r;
+    }
+    if (opt) return;
+    const int64_t c0 = (int64_t)blockIdx.x * strip;
+    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    VI best{LPX_INF, LPX_NOIDX};
+    double rowmin = LPX_INF;
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
+        const double row = (s.var_state[j] == LPX_VS_BASIC) ? 0.0 : s.T[r * s.ld + j];
+        const double th = lpx_dsd(s.T[s.m * s.ld + j], row, f32);
+        if (vi_less(th, s.col0 + j, best.v, best.i)) { best.v = th; best.i = s.col0 + j; }
+        rowmin = fmin(rowmin, row);
+    }
+    best = block_argmin(best, red);
+    rowmin = block_min(rowmin, red);
+    if (threadIdx.x == 0) {
+        P.v0[blockIdx.x] = best.v;
+        P.i0[blockIdx.x] = best.i;
+        P.v1[blockIdx.x] = rowmin;
+    }
+}
+
+// shared tail of the dual prepare kernels: eta column from the entering column d (d[m] = its reduced cost), copy of
+// the old pivot row, bookkeeping
+__device__ __forceinline__ void td_finish(const lpx_tableau &s, int64_t r, int64_t j, double dr, double di, double theta,
+                                          double rowmin, double *d, double *e, double *rowr)
+{
+    lpx_ctrl *ctrl = s.ctrl;
+    const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (gi <= s.m) {
+        d[gi] = di;
+        e[gi] = (gi == r) ? 1.0 / dr : (-di) / dr; // primal_solvers.py:236-244; e[m] eliminates rc_j
+    }
+    if (gi < lpx_roundup_dev(s.n + 1, 2)) rowr[gi] = s.T[r * s.ld + gi];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t leaving = s.basis[r];
+        s.basis[r] = j;
+        const int64_t ll = leaving - s.col0, jl = j - s.col0;
+        if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
+        if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+        if (s.log && ctrl->pivots < s.log_cap) {
+            s.log[3 * ctrl->pivots + 0] = r;
+            s.log[3 * ctrl->pivots + 1] = j;
+            s.log[3 * ctrl->pivots + 2] = leaving;
+        }
+        ctrl->pivots += 1;
+        ctrl->enter_j = j;
+        ctrl->leave_var = leaving;
+        ctrl->ratio_val = theta;
+        ctrl->aux_val = rowmin;
+        ctrl->flip = 0;
+        ctrl->f32_phase = 0;
+    }
+}
+
+// unpartitioned: entering decision from the strip partials, dual unboundedness (:41-44, :56-59), column gather
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_prepare(lpx_tableau s, Partials P, int64_t nprice, double *d, double *e,
+                                                         double *rowr)
+{
+    __shared__ BlockRed red;
+    lpx_ctrl *ctrl = s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const VI t = combine_argmin(P.v0, P.i0, nprice, red);
+    const double rowmin = combine_min(P.v1, nprice, red);
+    if (rowmin >= 0.0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->aux_val = rowmin;
+            ctrl->status = LPX_DUAL_UNBOUNDED;
+        }
+        return;
+    }
+    const int64_t r = ctrl->leave_r, j = t.i; // leave_r: written by k_td_ratio, only read here
+    const double dr = s.T[r * s.ld + (j - s.col0)];
+    const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const double di = (gi <= s.m) ? s.T[gi * s.ld + (j - s.col0)] : 0.0;
+    td_finish(s, r, j, dr, di, t.v, rowmin, d, e, rowr);
+}
+
+// column-partitioned, part 1: local proposal (min theta, its global column, that column of T)
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_propose(lpx_tableau s, Partials P, int64_t nprice, double *sendbuf)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const VI t = combine_argmin(P.v0, P.i0, nprice, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sendbuf[0] = t.v;
+        sendbuf[1] = (double)t.i;
+    }
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i <= s.m) sendbuf[2 + i] = s.T[i * s.ld + (t.i - s.col0)];
+}
+
+// column-partitioned, part 2: global entering column = first argmin of theta over the ranks' proposals (ranks own
+// ascending column ranges, so "lowest global index on ties" is np.argmin's first minimum).  No candidate anywhere
+// (every theta = +inf) is exactly min(row) >= 0: dual unbounded.
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_commit(lpx_tableau s, const double *recv, int64_t nranks, int64_t msg, double *d,
+                                                        double *e, double *rowr)
+{
+    lpx_ctrl *ctrl = s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    VI best{LPX_INF, LPX_NOIDX};
+    int64_t win = 0;
+    for (int64_t g = 0; g < nranks; ++g) {
+        const double v = recv[g * msg];
+        const int64_t idx = (int64_t)recv[g * msg + 1];
+        if (vi_less(v, idx, best.v, best.i)) { best.v = v; best.i = idx; win = g; }
+    }
+    if (best.v == LPX_INF) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->aux_val = 0.0;
+            ctrl->status = LPX_DUAL_UNBOUNDED;
+        }
+        return;
+    }
+    const int64_t r = ctrl->leave_r;
+    const double *col = recv + win * msg + 2;
+    const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    td_finish(s, r, best.i, col[r], (gi <= s.m) ? col[gi] : 0.0, best.v, -1.0, d, e, rowr);
+}
+
+static void td_launch_select(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st)
+{
+    const int64_t nrow = lpx_cdiv(s->m, LPX_BLOCK), strip = 2 * (int64_t)p.threads * p.vpt;
+    hipLaunchKernelGGL(k_td_row, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.ratio);
+    hipLaunchKernelGGL(k_td_ratio, dim3(p.grid.x), dim3(LPX_BLOCK), 0, st, *s, w.ratio, nrow, w.price, strip);
+}
+
+extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(s->col0 == 0 && s->n_global == s->n, "lpx_tableau_dual_iterate needs an unpartitioned tableau");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    if (iters <= 0) return LPX_OK;
+    const lpx_tableau sv = *s;
+    auto one = [&](hipStream_t q) {
+        td_launch_select(&sv, w, plan, q);
+        hipLaunchKernelGGL(k_td_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(&sv), LPX_BLOCK)), dim3(LPX_BLOCK), 0, q, sv, w.price,
+                           (int64_t)plan.grid.x, w.d, w.e, w.rowr);
+        t_launch_update(&sv, w, plan, q);
+    };
+    TabKey key;
+    memset(&key, 0, sizeof key);
+    key.s = sv; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt; key.threads = plan.threads;
+    key.rpb = plan.rows_per_block; key.what = 2;
+    return lpx_run_iterations(&key, sizeof key, iters, st, one);
+}
+
+extern "C" int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    td_launch_select(s, w, plan, st);
+    hipLaunchKernelGGL(k_td_propose, dim3((unsigned)lpx_cdiv(s->m + 1, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.price,
+                       (int64_t)plan.grid.x, sendbuf);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    hipLaunchKernelGGL(k_td_commit, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks,
+                       lpx_tableau_msg_len(s->m), w.d, w.e, w.rowr);
+    t_launch_update(s, w, plan, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 // primal_solvers.py:72-79 on the tableau's replicated x_B column
 __global__ __launch_bounds__(LPX_BLOCK) void k_t_fill(double *x, int64_t n)
 {

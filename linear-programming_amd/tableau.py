@@ -15,7 +15,8 @@ import numpy as np
 from . import _lib
 from .data_classes import LinProgResult
 from .device import roundup, stream_ptr, to_device, torch_cuda
-from .exceptions import BasisIsPrimalInfeasibleError, PrimalIsUnboundedError
+from .exceptions import (BasisIsDualInfeasibleError, BasisIsPrimalInfeasibleError, DualIsUnboundedError,
+                         PrimalIsUnboundedError)
 from .preprocessing import ProblemPreprocessingUtils
 
 
@@ -61,8 +62,9 @@ class TableauEngine:
     FIRST_CHUNK = 16
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
-                 group=None, pricing="first_negative"):
+                 group=None, pricing="first_negative", dual=False):
         torch = torch_cuda()
+        self.dual = bool(dual)
         self.torch = torch
         self.lib = _lib.load()
         self.m, self.n = int(m), int(n_local)
@@ -142,9 +144,16 @@ class TableauEngine:
         """Enqueue `iters` pivots without any host synchronisation."""
         st = stream_ptr()
         if self.group is None:
-            _lib.check(self.lib.lpx_tableau_iterate(C.byref(self.s), int(iters), st))
+            f = self.lib.lpx_tableau_dual_iterate if self.dual else self.lib.lpx_tableau_iterate
+            _lib.check(f(C.byref(self.s), int(iters), st))
             return
         ex = self.exchange
+        if self.dual:
+            for it in range(int(iters)):
+                _lib.check(self.lib.lpx_tableau_dual_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))
+                ex.all_gather()
+                _lib.check(self.lib.lpx_tableau_dual_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
+            return
         for it in range(int(iters)):
             # the update kernel of the previous pivot leaves the pricing partials behind; only the first pivot of a
             # call rescans the reduced-cost row (the caller may have touched T in between)
@@ -251,3 +260,40 @@ class PrimalTableauSimplexSolver:
 
     def pivot_log(self):
         return self._engine.host_log(self._engine.read_ctrl().pivots)
+
+
+class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
+    """``DualRevisedSimplexSolver`` semantics (dual_solvers.py:9-120) on the carried tableau: the constructor checks
+    dual feasibility of the starting basis (:14-16), ``solve`` runs the dual simplex (:82-108) and raises
+    ``DualIsUnboundedError`` (:41-44).  ``optimum`` stays ``None`` until optimality is reached, as in the reference.
+    ``group`` column-partitions the tableau exactly as for the primal solver."""
+
+    def __init__(self, c, A, b, basis, group=None):
+        self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
+        self.m, self.n = A32.shape
+        self.basis = np.array(basis).astype(int)
+        inv32 = np.linalg.inv(A32[:, self.basis])  # primal_solvers.py:37
+        bfs32 = inv32 @ self.b
+        if not np.all(self.c[self.basis] @ inv32 @ A32 <= self.c):  # dual_solvers.py:14-16
+            raise BasisIsDualInfeasibleError
+        j0, j1 = 0, self.n
+        if group is not None:
+            import torch.distributed as dist
+
+            j0, j1 = column_range(self.n, dist.get_rank(group), dist.get_world_size(group))
+        self.counter = None
+        self.optimum = None
+        self._engine = TableauEngine.from_columns(A32[:, j0:j1], self.b, self.c, self.basis, j0, self.n, inv32=inv32,
+                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group, dual=True)
+
+    def solve(self, maxiters: int = 100):
+        self.counter = 0
+        ctrl = self._engine.run(maxiters)
+        self.counter = int(ctrl.counter)
+        self.basis[:] = self._engine.host_basis()
+        if ctrl.status == _lib.DUAL_UNBOUNDED:
+            raise DualIsUnboundedError
+        if ctrl.status == _lib.OPTIMAL:
+            self.optimum = True
+        x, cost = self._engine.expand()
+        return LinProgResult(x=x, basis=self.basis, cost=cost, iters=self.counter, optimum=self.optimum)

@@ -625,6 +625,58 @@ int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
     return s->status;
 }
 
+/* Dual simplex on the carried tableau: DualNaiveSimplexSolver.solve (dual_solvers.py:82-108) with the rules of
+ * :47-80 read off T -- leaving row = first x_B < 0 (column n), dual row = row r of T with basic columns forced to 0
+ * (:39), reduced costs = row m, ratio test (-rc_j)/row_j over row_j < 0, first argmin; then the same pivot as
+ * lpo_tableau_solve. */
+int lpo_tableau_dual_solve(lpo_tableau *s, int64_t maxiters)
+{
+    const int64_t m = s->m, n = s->n, ld = s->ld;
+    double *xcol = (double *)malloc(sizeof(double) * (size_t)m);
+    double *row = (double *)malloc(sizeof(double) * (size_t)n);
+    s->counter = 0;
+    s->status = LPO_RUNNING;
+    while (s->counter < maxiters) {
+        s->counter += 1;
+        for (int64_t i = 0; i < m; ++i) xcol[i] = s->T[i * ld + n];
+        double mn;
+        int64_t r;
+        if (lpo_dual_row_select(xcol, m, &mn, &r)) { /* dual_solvers.py:47-54 */
+            s->status = LPO_OPTIMAL;
+            break;
+        }
+        for (int64_t k = 0; k < n; ++k) row[k] = (s->var_state[k] == VS_BASIC) ? 0.0 : s->T[r * ld + k]; /* :38-39 */
+        int64_t j;
+        double theta, rowmin;
+        lpo_ratio_dual(s->T + m * ld, row, s->var_state, n, s->f32_phase, &j, &theta, &rowmin); /* :61-80 */
+        if (rowmin >= 0) { /* :41-44 */
+            s->status = LPO_DUAL_UNBOUNDED;
+            break;
+        }
+        for (int64_t i = 0; i <= m; ++i) s->d[i] = s->T[i * ld + j];
+        const double dr = s->d[r];
+        for (int64_t i = 0; i <= m; ++i) s->e[i] = (-s->d[i]) / dr; /* primal_solvers.py:236-244 */
+        s->e[r] = 1.0 / dr;
+        const int64_t leaving = s->basis[r];
+        if (s->log && s->pivots < s->log_cap) {
+            s->log[3 * s->pivots + 0] = r;
+            s->log[3 * s->pivots + 1] = j;
+            s->log[3 * s->pivots + 2] = leaving;
+        }
+        s->pivots += 1;
+        s->basis[r] = j;
+        s->var_state[leaving] = VS_LOWER;
+        s->var_state[j] = VS_BASIC;
+        if (s->threads > 1) lpo_rank1_update_mt(s->T, m + 1, n + 1, ld, r, s->e, s->rowr);
+        else lpo_rank1_update(s->T, m + 1, n + 1, ld, r, s->e, s->rowr);
+        for (int64_t i = 0; i <= m; ++i) s->T[i * ld + j] = (i == r) ? 1.0 : 0.0;
+        s->f32_phase = 0;
+    }
+    free(xcol);
+    free(row);
+    return s->status;
+}
+
 /* primal_solvers.py:72-79: x = scatter(x_B at basis); cost = dot(c, x) (float64 accumulate, index order). */
 double lpo_expand_and_cost(const double *xB, const int64_t *basis, const float *c, int64_t m, int64_t n,
                            double *x)

@@ -83,6 +83,8 @@ def lib():
         L.lpo_dual_row.argtypes = [C.POINTER(_Revised), C.c_int64]
         L.lpo_dual_row.restype = None
         L.lpo_tableau_solve.argtypes = [C.POINTER(_Tableau), C.c_int64]
+        L.lpo_tableau_dual_solve.argtypes = [C.POINTER(_Tableau), C.c_int64]
+        L.lpo_tableau_dual_solve.restype = C.c_int
         L.lpo_rank1_update.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _dp, _dp]
         L.lpo_rank1_update.restype = None
         L.lpo_rank1_update_mt.argtypes = L.lpo_rank1_update.argtypes
@@ -402,7 +404,10 @@ class OraclePrimalDual:
 class OracleTableau:
     """Tableau-form restatement (lpo_tableau_solve): carries T = B^-1 A, x_B and the reduced-cost row."""
 
-    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0):
+    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0, kind="primal"):
+        """kind = "dual": the dual simplex rules on the same tableau (lpo_tableau_dual_solve); the constructor then
+        checks dual instead of primal feasibility of the starting basis (dual_solvers.py:14-16)."""
+        self.kind = kind
         self.c, A32, self.b = preprocess(c, A, b)
         self.m, self.n = A32.shape
         m, n = self.m, self.n
@@ -411,6 +416,8 @@ class OracleTableau:
         self.T = np.zeros((m + 1, self.ld))
         B = A32[:, self.basis]
         if np.array_equal(B, np.eye(m, dtype=np.float32)):
+            if check and kind == "dual" and not np.all(self.c[self.basis] @ A32 <= self.c):
+                raise ValueError("BasisIsDualInfeasibleError")
             self.T[:m, :n] = A32
             self.T[:m, n] = self.b
             self.T[m, :n] = self.c.astype(np.float64) - (self.c[self.basis].astype(np.float64) @ self.T[:m, :n]
@@ -419,8 +426,10 @@ class OracleTableau:
         else:
             inv32 = np.linalg.inv(B)
             bfs32 = inv32 @ self.b
-            if check and not np.all(bfs32 >= 0.0):
+            if check and kind == "primal" and not np.all(bfs32 >= 0.0):
                 raise ValueError("BasisIsPrimalInfeasibleError")
+            if check and kind == "dual" and not np.all(self.c[self.basis] @ inv32 @ A32 <= self.c):
+                raise ValueError("BasisIsDualInfeasibleError")
             self.T[:m, :n] = inv32 @ A32
             self.T[:m, n] = bfs32
             rc32 = self.c - self.c[self.basis] @ inv32 @ A32
@@ -441,7 +450,8 @@ class OracleTableau:
         s.pricing = int(pricing)
 
     def solve(self, maxiters=100):
-        status = lib().lpo_tableau_solve(C.byref(self.s), int(maxiters))
+        f = lib().lpo_tableau_solve if self.kind == "primal" else lib().lpo_tableau_dual_solve
+        status = f(C.byref(self.s), int(maxiters))
         xB = np.ascontiguousarray(self.T[: self.m, self.n])
         x, cost = expand_and_cost(xB, self.basis, self.c, self.n)
         p = int(self.s.pivots)

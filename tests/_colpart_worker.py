@@ -67,11 +67,96 @@ def numpy_rank(c, A, b, basis, rank, world, ex, maxiters):
     return log, basis, T[:m, nl].copy(), False
 
 
+def numpy_rank_dual(c, A, b, basis, rank, world, ex, maxiters):
+    """Column-partitioned DUAL tableau simplex with NumPy standing in for lpx_tableau_dual_propose/commit."""
+    c32, A32, b32 = O.preprocess(c, A, b)
+    m, n = A32.shape
+    j0, j1 = column_range(n, rank, world)
+    nl = j1 - j0
+    basis = np.array(basis, dtype=np.int64)
+    inv32 = np.linalg.inv(A32[:, basis])
+    T = np.zeros((m + 1, nl + 1))
+    T[:m, :nl] = (inv32 @ A32)[:, j0:j1]
+    T[:m, nl] = inv32 @ b32
+    T[m, :nl] = (c32 - c32[basis] @ inv32 @ A32)[j0:j1]
+    isbasic = np.zeros(n, dtype=bool)
+    isbasic[basis] = True
+    T[m, :nl][isbasic[j0:j1]] = 0.0
+    log = []
+    f32 = True
+    for it in range(maxiters):
+        xB = T[:m, nl]
+        mn = xB.min()
+        if mn >= 0 or abs(mn) <= 1e-8:
+            return log, basis, xB.copy(), "optimal"
+        r = int(np.flatnonzero(xB < 0)[0])  # replicated decision
+        row = np.where(isbasic[j0:j1], 0.0, T[r, :nl])
+        rc = T[m, :nl]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if f32:
+                th = np.where(row < 0, ((-rc.astype(np.float32)) / row.astype(np.float32)).astype(np.float64), np.inf)
+            else:
+                th = np.where(row < 0, (-rc) / row, np.inf)
+        send = np.zeros(ex.msg)
+        k = int(np.argmin(th)) if nl else 0
+        send[0] = th[k] if nl else np.inf
+        send[1] = j0 + k
+        if nl:
+            send[2:2 + m + 1] = T[:, k]
+        ex.sendbuf.copy_(torch.from_numpy(send))
+        recv = ex.all_gather().numpy().reshape(world, ex.msg)
+        if np.all(np.isinf(recv[:, 0])):
+            return log, basis, xB.copy(), "dual_unbounded"
+        win = min(range(world), key=lambda g: (recv[g, 0], recv[g, 1]))
+        j = int(recv[win, 1])
+        d = recv[win, 2:2 + m + 1]
+        e = (-d) / d[r]
+        e[r] = 1.0 / d[r]
+        log.append([r, j, int(basis[r])])
+        isbasic[basis[r]] = False
+        isbasic[j] = True
+        basis[r] = j
+        T = O.rank1_update(np.ascontiguousarray(T), r, e)
+        if j0 <= j < j1:
+            T[:, j - j0] = 0.0
+            T[r, j - j0] = 1.0
+        f32 = False
+    return log, basis, T[:m, nl].copy(), "running"
+
+
+def main_dual(mode, m, n, seed, maxiters):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    c, A, b, basis = problems.gen_dual(m, n, seed)
+    want = O.OracleTableau(c, A, b, basis, kind="dual", log_cap=maxiters + 1).solve(maxiters)
+    assert len(want.log) > 3
+    if mode == "cpu-dual":
+        ex = ProposalExchange(dist.group.WORLD, m + 3 + ((m + 3) % 2), "cpu")
+        log, bas, xB, how = numpy_rank_dual(c, A, b, basis, rank, world, ex, maxiters)
+        assert log == want.log.tolist(), f"rank {rank}: pivot sequence differs"
+        assert bas.tolist() == want.basis.tolist() and (how == "optimal") == (want.status == O.OPTIMAL)
+    else:
+        from linprog_amd.tableau import DualTableauSimplexSolver
+
+        torch.cuda.set_device(0)
+        cls = type("L", (DualTableauSimplexSolver,), {"_LOG_CAP": maxiters + 1})
+        s = cls(c, A, b, basis, group=dist.group.WORLD)
+        res = s.solve(maxiters)
+        assert s.pivot_log().tolist() == want.log.tolist(), f"rank {rank}: pivot sequence differs"
+        assert res.basis.tolist() == want.basis.tolist() and (res.optimum is True) == (want.status == O.OPTIMAL)
+        assert np.allclose(res.x, want.x, rtol=1e-9, atol=1e-9) and abs(res.cost - want.cost) <= 1e-9 * max(1, abs(want.cost))
+
+
 def main():
     mode = sys.argv[1]
     m, n, seed, maxiters = (int(v) for v in sys.argv[2:6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode.endswith("-dual"):
+        main_dual(mode, m, n, seed, maxiters)
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"rank {rank} ok")
+        return
     c, A, b, basis = problems.gen_primal(m, n, seed)
     want = O.OracleRevised(c, A, b, basis, log_cap=maxiters + 1).solve(maxiters)
     if mode == "cpu":

@@ -36,3 +36,14 @@ def test_protocol_cpu_gloo(nproc, m, n):
 @pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
 def test_product_path_two_ranks_one_gpu(nproc, m, n):
     _run("gpu", nproc, m, n, 2, 100000)
+
+
+@pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
+def test_dual_protocol_cpu_gloo(nproc, m, n):
+    _run("cpu-dual", nproc, m, n, 1, 100000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
+def test_dual_product_path_two_ranks_one_gpu(nproc, m, n):
+    _run("gpu-dual", nproc, m, n, 2, 100000)

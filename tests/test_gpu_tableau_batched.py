@@ -172,3 +172,61 @@ def test_tableau_dantzig_opt_in_matches_oracle(m, n, seed):
         ref = O.OracleTableau(c, A, b, basis).solve(100000)
         assert abs(ref.cost - res.cost) <= 1e-9 * max(1.0, abs(ref.cost))
         assert res.iters <= ref.iters
+
+
+DUAL_CASES = [c for c in load("random.json") + load("textbook.json") if c["solver"].startswith("Dual")]
+
+
+@pytest.mark.parametrize("cs", DUAL_CASES, ids=case_id)
+def test_dual_tableau_matches_reference(cs):
+    """DualTableauSimplexSolver takes DualNaive/DualRevisedSimplexSolver's pivots (goldens), raises where they raise,
+    and is bit-identical to the oracle's dual tableau loop."""
+    from linprog_amd import exceptions
+    from linprog_amd.tableau import DualTableauSimplexSolver
+    from oracle import oracle as O
+
+    ref = cs["ref"]
+    c, A, b, basis = problem_of(cs)
+    if ref["exception"] == "BasisIsDualInfeasibleError":
+        with pytest.raises(exceptions.BasisIsDualInfeasibleError):
+            DualTableauSimplexSolver(c, A, b, basis)
+        return
+    cap = max(16, len(ref["pivots"]) + 1)
+    Solver = type("T", (DualTableauSimplexSolver,), {"_LOG_CAP": cap})
+    solver = Solver(c, A, b, basis)
+    maxiters = cs.get("maxiters", 100)
+    o = O.OracleTableau(c, A, b, basis, kind="dual", log_cap=cap)
+    ro = o.solve(maxiters)
+    if ref["exception"]:
+        with pytest.raises(getattr(exceptions, ref["exception"])):
+            solver.solve(maxiters)
+        assert solver.pivot_log().tolist() == ref["pivots"]
+        return
+    res = solver.solve(maxiters)
+    assert solver.pivot_log().tolist() == ref["pivots"] == ro.log.tolist()
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"]
+    assert res.basis.tolist() == ref["basis"]
+    if "Naive" in cs["solver"]:  # the naive reference re-inverts in float32 every pivot: values are float32-accurate
+        assert np.allclose(res.x, ref["x"], rtol=1e-5, atol=1e-5) and abs(res.cost - ref["cost"]) < 1e-5
+    else:
+        assert_close(res.x, ref["x"], "x")
+        assert_close(res.cost, ref["cost"], "cost")
+    assert np.array_equal(res.x, ro.x)  # the cost is a tree dot on the device, sequential in the oracle
+    assert abs(res.cost - ro.cost) <= 1e-13 * max(1.0, abs(ro.cost))
+
+
+@pytest.mark.parametrize("m,n,seed", [(300, 700, 5), (1000, 2000, 6)])
+def test_dual_tableau_larger_vs_oracle(m, n, seed):
+    """Multi-strip sizes (several workgroups per reduction, hipGraph replay): sequence and values against the oracle."""
+    from linprog_amd.tableau import DualTableauSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_dual(m, n, seed)
+    Solver = type("T", (DualTableauSimplexSolver,), {"_LOG_CAP": 4096})
+    solver = Solver(c, A, b, basis)
+    res = solver.solve(600)
+    ro = O.OracleTableau(c, A, b, basis, kind="dual", log_cap=4096).solve(600)
+    assert solver.pivot_log().tolist() == ro.log.tolist() and len(ro.log) > 50
+    assert res.iters == ro.iters
+    assert_close(res.x, ro.x, "x")
+    assert_close(res.cost, ro.cost, "cost")
