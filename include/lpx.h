@@ -213,6 +213,20 @@ int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, void *stream
 /* Part 2, after an all-gather of the proposals: global first argmin of theta, update of the local slice. */
 int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);
 
+/* ------------------------------------------------------- opt-in: fp64 refinement of the product-form inverse */
+/* No counterpart in the reference's revised solvers, which multiply eta matrices for the whole solve
+ * (primal_solvers.py:247-249); its only reinversion is the naive solvers' np.linalg.inv per pivot (:92-94).
+ * `steps` Newton-Schulz steps X <- X + X (I - B X), B = A[:, basis], on the matrix cores (fp64 MFMA GEMM).
+ * resid: 2 device doubles, max|I - B X| before and after.  update_xB != 0 also recomputes x_B = B^-1 b in fp64.
+ * Clears the float32 phase.  Never called by solve(): callers opt in. */
+int64_t lpx_refine_workspace_bytes(int64_t m);
+int lpx_revised_refine(const lpx_revised *s, int64_t steps, int update_xB, void *work, int64_t work_bytes,
+                       double *resid, void *stream);
+/* The GEMM behind it: D = alpha * op(A) B + beta * C + gamma * I, fp64 row-major, op(A) = A^T when transa (A is then
+ * stored K x M).  C may be NULL.  v_mfma_f64_16x16x4_f64, LDS-tiled. */
+int lpx_dgemm(int transa, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+              int64_t ldb, double beta, const double *C, int64_t ldc, double gamma, double *D, int64_t ldd, void *stream);
+
 /* ------------------------------------------------------------------------------------ batched small LPs */
 /* PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) (primal_solvers.py:176-263) for `batch` independent
  * LPs of one shape, slack or general start basis (Binv0 = B^-1 per LP, or NULL for the identity).  Arrays are

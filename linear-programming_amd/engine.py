@@ -109,6 +109,18 @@ class RevisedEngine:
     def bounded_update_bfs(self):
         _lib.check(self.lib.lpx_bounded_update_bfs(C.byref(self.s), stream_ptr()))
 
+    def refine(self, steps=1, update_xB=True):
+        """Opt-in: `steps` Newton-Schulz steps on B^-1 in fp64 on the matrix cores (lpx_revised_refine).  Returns
+        (max|I - B X| before, after).  Not part of the reference's algorithm; solve() never calls it."""
+        torch = self.torch
+        nbytes = self.lib.lpx_refine_workspace_bytes(self.m)
+        work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        resid = torch.zeros(2, dtype=torch.float64, device="cuda")
+        _lib.check(self.lib.lpx_revised_refine(C.byref(self.s), int(steps), int(bool(update_xB)), work.data_ptr(), nbytes,
+                                               resid.data_ptr(), stream_ptr()))
+        r = resid.cpu().numpy()
+        return float(r[0]), float(r[1])
+
     # ------------------------------------------------------------------ results
     def expand(self):
         """(x, cost) on the host: scatter + dot on the device, one D2H copy (primal_solvers.py:72-79)."""

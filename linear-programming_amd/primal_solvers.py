@@ -97,6 +97,14 @@ class PrimalNaiveSimplexSolver:
         self._engine.pivot(col_in_basis_to_leave_basis, col_in_A_to_enter_basis)
         self._sync_basis()
 
+    def refine_inverse(self, steps=1):
+        """Opt-in extension (no counterpart in the reference, which carries the product-form inverse for the whole solve):
+        Newton-Schulz refinement of ``inv_basis_matrix`` and recomputation of ``bfs`` in float64 on the device.  Returns
+        ``(max|I - B B^-1| before, after)``.  Meant for very long runs; ``solve()`` never calls it."""
+        if self._NAIVE:
+            raise ValueError("the naive solvers re-invert every pivot; there is nothing to refine")
+        return self._engine.refine(steps=steps, update_xB=True)
+
     def _raise_for_status(self, status):
         if status == _lib.PRIMAL_UNBOUNDED:
             raise PrimalIsUnboundedError  # primal_solvers.py:130-132

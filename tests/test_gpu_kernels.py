@@ -129,3 +129,30 @@ def test_float32_ratio_tie_breaks_like_reference(env):
     assert oi.cpu().numpy()[0] == 0
     lib.check(L.lpx_ratio_primal(x_d.data_ptr(), d_d.data_ptr(), 2, 0, ov.data_ptr(), oi.data_ptr(), sp, None))
     assert oi.cpu().numpy()[0] == 1
+
+
+@pytest.mark.parametrize("transa", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (100, 70, 33), (129, 257, 65), (1000, 1000, 1000), (3000, 3000, 1500)])
+def test_dgemm_mfma_vs_numpy(env, M, N, K, transa):
+    """lpx_dgemm (fp64 MFMA, both tile sizes, ragged edges, op(A) = A or A^T, beta*C and gamma*I terms) against numpy.
+    Floating point: |err| <= 1e-13 * K * max|a||b| (summation order differs from BLAS)."""
+    lib, torch = env["L"], env["torch"]
+    rng = np.random.default_rng(M * 7 + N * 3 + K + transa)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N))
+    alpha, beta, gamma = -1.25, 0.5, 2.0
+    want = alpha * (A @ B) + beta * Cm + gamma * np.eye(M, N)
+    As = np.ascontiguousarray(A.T) if transa else A
+    dA, dB, dC = (torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (As, B, Cm))
+    dD = torch.zeros((M, N), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.lpx_dgemm(transa, M, N, K, alpha, dA.data_ptr(), As.shape[1], dB.data_ptr(), N, beta, dC.data_ptr(), N, gamma,
+                       dD.data_ptr(), N, st)
+    assert rc == 0
+    got = dD.cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-13 * K * 16
+    # C = NULL path
+    rc = lib.lpx_dgemm(transa, M, N, K, 1.0, dA.data_ptr(), As.shape[1], dB.data_ptr(), N, 0.0, None, 0, 0.0, dD.data_ptr(), N, st)
+    assert rc == 0
+    assert np.max(np.abs(dD.cpu().numpy() - A @ B)) <= 1e-13 * K * 16
