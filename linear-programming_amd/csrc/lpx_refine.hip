@@ -29,7 +29,7 @@ struct GemmArgs {
 // conflict-free read of consecutive doubles.  The next K-tile is fetched into registers while the current one is
 // multiplied (an fp64 MFMA occupies a SIMD for 64 cycles: a K-tile is >= 4 k cycles of matrix work per wave).
 template <int WT, bool TRANSA>
-__global__ __launch_bounds__(256) void k_dgemm(GemmArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dgemm(GemmArgs g)
 {
     constexpr int TM = WT * 32, TN = WT * 32, LDT = TM + 4;
     constexpr int PER = TM * GEMM_KT / 256; // doubles per lane per operand tile: 4 (WT=4) or 2 (WT=2)
@@ -94,18 +94,24 @@ __global__ __launch_bounds__(256) void k_dgemm(GemmArgs g)
     for (int64_t kt = 0; kt < ntile; ++kt) {
         const int buf = (int)(kt & 1);
         if (kt + 1 < ntile) fetch((kt + 1) * GEMM_KT);
+        // operands of step k4+1 are read from LDS while the 16 MFMAs of step k4 run
+        double a[2][WT], b[2][WT];
+        auto operands = [&](int k4, int slot) {
+            const int kk = k4 * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) a[slot][i] = As[buf][kk][wm + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) b[slot][j] = Bs[buf][kk][wn + j * 16 + (lane & 15)];
+        };
+        operands(0, 0);
 #pragma unroll
         for (int k4 = 0; k4 < GEMM_KT / 4; ++k4) {
-            const int kk = k4 * 4 + (lane >> 4);
-            double a[WT], b[WT];
-#pragma unroll
-            for (int i = 0; i < WT; ++i) a[i] = As[buf][kk][wm + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < WT; ++j) b[j] = Bs[buf][kk][wn + j * 16 + (lane & 15)];
+            if (k4 + 1 < GEMM_KT / 4) operands(k4 + 1, (k4 + 1) & 1);
 #pragma unroll
             for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4 & 1][i], b[k4 & 1][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < ntile) stage(buf ^ 1); // the other buffer: last read one barrier ago
         __syncthreads();
