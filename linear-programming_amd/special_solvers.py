@@ -135,12 +135,18 @@ class PrimalDualAlgorithm:
         self.m, self.n = self.A.shape
         self.counter = 0
         self.optimum = False
+        self.inner_pivots = 0  # basis changes of all restricted-primal solves so far
         self.inner_pivot_logs = []  # (row, entering, leaving) in [A | I] numbering, when _LOG_CAP > 0
         self.admissible_sets = []
 
     _LOG_CAP = 0
 
-    def solve(self, maxiters1: int = 100, maxiters2: int = 100):
+    def solve(self, maxiters1: int = 100, maxiters2: int = 100, warm_start: bool = False):
+        """``warm_start=True`` is an opt-in extension: the restricted primal keeps its optimal basis,
+        B^-1 and x_B from one outer iteration to the next instead of the reference's cold restart from the artificial
+        basis (special_solvers.py:408-425).  Its basic columns have zero reduced cost in the restricted primal, so they
+        stay admissible after the dual step and the old basis is a feasible start.  Same optimum, fewer inner pivots,
+        different pivot counts than the reference: never the default."""
         torch = torch_cuda()
         lib = _lib.load()
         y0 = np.zeros(self.m)
@@ -175,16 +181,23 @@ class PrimalDualAlgorithm:
         while self.counter < maxiters1:
             self.counter += 1
             _lib.check(lib.lpx_pd_admissible(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, v.data_ptr(), st))  # :405
-            # fresh restricted-primal solver state (:408-424): artificial basis, B^-1 = I, bfs = b, float32 phase
-            eng.var_state[n:] = _lib.VS_BASIC
-            eng.Binv.zero_()
-            eng.Binv[:, :m].copy_(eye)
-            eng.xB.copy_(b_dev)
-            eng.basis.copy_(art_dev)
-            _lib.check(lib.lpx_ctrl_init(eng.s.ctrl, 1, st))
+            if warm_start and self.counter > 1:
+                # keep basis / B^-1 / x_B; artificials that left the basis stay available at their bound, and the
+                # basic columns are basic whatever isclose() says about them to the last bit
+                eng.var_state[n:] = _lib.VS_LOWER
+                eng.var_state[eng.basis] = _lib.VS_BASIC
+            else:
+                # fresh restricted-primal solver state (:408-424): artificial basis, B^-1 = I, bfs = b, float32 phase
+                eng.var_state[n:] = _lib.VS_BASIC
+                eng.Binv.zero_()
+                eng.Binv[:, :m].copy_(eye)
+                eng.xB.copy_(b_dev)
+                eng.basis.copy_(art_dev)
+                _lib.check(lib.lpx_ctrl_init(eng.s.ctrl, 1, st))
             if self._LOG_CAP:
                 self.admissible_sets.append(np.flatnonzero(eng.host_var_state()[:n] == _lib.VS_LOWER))
             ctrl = eng.run(_lib.KIND_PRIMAL, maxiters2)  # :425
+            self.inner_pivots += int(ctrl.counter) - (1 if ctrl.status == _lib.OPTIMAL else 0)
             if ctrl.status == _lib.PRIMAL_UNBOUNDED:
                 raise PrimalIsUnboundedError
             if self._LOG_CAP:

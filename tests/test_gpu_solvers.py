@@ -273,3 +273,28 @@ def test_refine_inverse_restores_a_drifted_inverse(m, n, seed):
         Bm = A32[:, eng.host_basis()]
         assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(m))) < 1e-9
         assert np.max(np.abs(A32 @ res.x - np.asarray(b, dtype=np.float32))) < 1e-8
+
+
+@pytest.mark.parametrize("m,n,seed", [(8, 16, 0), (16, 32, 1), (32, 64, 2), (64, 128, 3)])
+def test_primal_dual_warm_start_same_optimum_fewer_pivots(m, n, seed):
+    """Opt-in warm start of the restricted primal (no counterpart in the reference): same optimal cost as the default
+    cold-restart mode and as HiGHS, x feasible, and no more inner pivots than the cold mode."""
+    from scipy.optimize import linprog
+    from linprog_amd.special_solvers import PrimalDualAlgorithm
+
+    c, A, b, _ = gen.gen_dual(m, n, seed)
+    cold = PrimalDualAlgorithm(c, A, b)
+    rc = cold.solve(100000, 100000)
+    warm = PrimalDualAlgorithm(c, A, b)
+    rw = warm.solve(100000, 100000, warm_start=True)
+    assert rc.optimum and rw.optimum
+    assert abs(rw.cost - rc.cost) <= 1e-9 * max(1.0, abs(rc.cost))
+    c32, A32, b32 = (np.asarray(v, dtype=np.float32).astype(float) for v in (c, A, b))
+    flip = b32 < 0
+    A32[flip] *= -1
+    b32[flip] *= -1
+    assert np.max(np.abs(A32 @ rw.x - b32)) < 1e-8 and rw.x.min() > -1e-10
+    ref = linprog(c32, A_eq=A32, b_eq=b32, bounds=(0, None), method="highs")
+    assert abs(rw.cost - ref.fun) <= 1e-8 * max(1.0, abs(ref.fun))
+    assert 0 < warm.inner_pivots <= cold.inner_pivots
+    print(f"inner pivots cold {cold.inner_pivots} warm {warm.inner_pivots}, outer {rc.iters} / {rw.iters}")
