@@ -663,12 +663,9 @@ template <int CPL, typename ColT, bool PARTIAL>
 static int batched_wave_launch2(const BatchArgs &a, hipStream_t stream)
 {
     const int64_t bytes = wave_lds(a.m, CPL, nullptr).bytes;
-    static int64_t configured = 0;
-    if (bytes > configured) {
-        LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT, PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes));
-        configured = bytes;
-    }
+    // per launch, not cached: the attribute belongs to the current device and a process may drive several
+    LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT, PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
     hipLaunchKernelGGL((k_batched_wave<CPL, ColT, PARTIAL>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
@@ -714,11 +711,7 @@ extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, con
         lpx_set_error("lpx_batched_primal_solve: LP needs %lld B of LDS, more than one CU has", (long long)bytes);
         return LPX_E_SIZE;
     }
-    static int64_t configured = 0;
-    if (bytes > configured) {
-        LPX_HIP(hipFuncSetAttribute((const void *)k_batched_primal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        configured = bytes;
-    }
+    LPX_HIP(hipFuncSetAttribute((const void *)k_batched_primal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(k_batched_primal, dim3((unsigned)batch), dim3(LPX_BLOCK), (size_t)bytes, (hipStream_t)stream, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;

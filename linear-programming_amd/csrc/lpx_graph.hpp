@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "lpx_device.hpp"
@@ -21,7 +22,7 @@ struct LpxGraphEntry {
 struct LpxGraphCache {
     std::mutex mu;
     std::vector<LpxGraphEntry> entries;
-    hipStream_t capture_stream = nullptr;
+    std::vector<std::pair<int, hipStream_t>> capture_streams; // one per device that ever captured
 };
 LpxGraphCache &lpx_graph_cache();
 
@@ -40,17 +41,26 @@ static int lpx_run_iterations(const void *key, size_t keylen, int64_t iters, hip
     if (use_graph) {
         LpxGraphCache &gc = lpx_graph_cache();
         std::lock_guard<std::mutex> lock(gc.mu);
+        int dev = 0;
+        LPX_HIP(hipGetDevice(&dev));
         std::vector<char> k((const char *)key, (const char *)key + keylen);
         k.push_back((char)U);
+        k.push_back((char)dev);
         hipGraphExec_t exec = nullptr;
         for (auto &e : gc.entries)
             if (e.key == k) exec = e.exec;
         if (!exec) {
-            if (!gc.capture_stream) LPX_HIP(hipStreamCreateWithFlags(&gc.capture_stream, hipStreamNonBlocking));
+            hipStream_t cs = nullptr;
+            for (auto &p : gc.capture_streams)
+                if (p.first == dev) cs = p.second;
+            if (!cs) {
+                LPX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                gc.capture_streams.push_back({dev, cs});
+            }
             hipGraph_t graph = nullptr;
-            LPX_HIP(hipStreamBeginCapture(gc.capture_stream, hipStreamCaptureModeRelaxed));
-            for (int u = 0; u < U; ++u) enqueue_one(gc.capture_stream);
-            LPX_HIP(hipStreamEndCapture(gc.capture_stream, &graph));
+            LPX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+            for (int u = 0; u < U; ++u) enqueue_one(cs);
+            LPX_HIP(hipStreamEndCapture(cs, &graph));
             LPX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             LPX_HIP(hipGraphDestroy(graph));
             if (gc.entries.size() >= 32) {

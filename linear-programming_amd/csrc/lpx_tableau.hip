@@ -417,7 +417,7 @@ static inline bool t_is_small(const lpx_tableau *s)
     if (lpx_env_int("LPX_TABLEAU_SMALL", 1) == 0) return false;
     // measured on MI355X: one workgroup gathers a strided column slower than many once m is beyond a few hundred
     // rows (m=1000: 11.4 us vs 3+3 us), so the single-workgroup form is kept for genuinely small tableaus
-    return s->m + 1 <= 512 && s->n + 2 <= 4096;
+    return s->m + 1 <= lpx_env_int("LPX_TABLEAU_SMALL_M", 512) && s->n + 2 <= 4096;
 }
 
 static inline int64_t t_prep_len(const lpx_tableau *s)
