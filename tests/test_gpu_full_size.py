@@ -82,3 +82,70 @@ def test_config3_batch_full_size():
     for i in range(0, B, 293):  # a spread sample is bit-identical to the oracle
         o = O.OracleRevised(*probs[i], log_cap=4).solve(100000)
         assert np.array_equal(res[i].x, o.x) and res[i].cost == o.cost and res[i].iters == o.iters
+
+
+def test_tableau_beyond_32bit_element_indices():
+    """A tableau of 4.6e9 doubles (36.9 GB, built on the device): element offsets exceed 2^32, so every index in K1 and
+    in the gather / copy kernels must be 64-bit.  Each pivot's decision and the updated tableau are checked against a
+    torch restatement of the same pivot kept in a second buffer (decisions exact, values to 1e-12: torch's addcmul is
+    not a fused multiply-add)."""
+    import torch
+
+    from linprog_amd import _lib
+    from linprog_amd.tableau import TableauEngine
+
+    m, n = 48000, 96000
+    ld = n + 2
+    assert (m + 1) * ld > 2 ** 32
+    g = torch.Generator(device="cuda").manual_seed(7)
+    T = torch.zeros((m + 1, ld), dtype=torch.float64, device="cuda")
+    k = n - m
+    for r0 in range(0, m, 4000):  # G ~ U(0,1) in float32-valued doubles, by row blocks
+        blk = torch.rand((min(4000, m - r0), k), generator=g, device="cuda", dtype=torch.float32)
+        T[r0:r0 + blk.shape[0], :k] = blk.to(torch.float64)
+    T[:m, k:n] = torch.eye(m, dtype=torch.float64, device="cuda")
+    T[:m, n] = 1.0 + torch.rand(m, generator=g, device="cuda", dtype=torch.float32).to(torch.float64)
+    c = torch.zeros(n, dtype=torch.float32, device="cuda")
+    c[:k] = -torch.rand(k, generator=g, device="cuda", dtype=torch.float32)
+    T[m, :n] = c.to(torch.float64)
+    basis = torch.arange(k, n, dtype=torch.int64, device="cuda")
+    vs = torch.full((n,), _lib.VS_LOWER, dtype=torch.int32, device="cuda")
+    vs[k:] = _lib.VS_BASIC
+    ref = T.clone()
+    eng = TableauEngine(T, m, n, basis, vs, c, log_cap=16)
+    pivots = 3
+    ctrl = eng.run(pivots)
+    assert ctrl.status == _lib.RUNNING and ctrl.pivots == pivots
+    log = eng.host_log(pivots)
+    f32 = True
+    for it in range(pivots):
+        rc = ref[m, :n]
+        j = int(torch.nonzero(rc < 0)[0])
+        d = ref[:, j].clone()
+        xB = ref[:m, n]
+        pos = d[:m] > 0
+        if f32:
+            th = torch.where(pos, (xB.to(torch.float32) / d[:m].to(torch.float32)).to(torch.float64), torch.inf)
+        else:
+            th = torch.where(pos, xB / d[:m], torch.inf)
+        r = int(torch.argmin(th))
+        assert [r, j] == log[it][:2].tolist(), f"pivot {it}"
+        e = -d / d[r]
+        e[r] = 1.0 / d[r]
+        rowr = ref[r].clone()
+        for r0 in range(0, m + 1, 8000):  # row blocks keep the temporaries small
+            r1 = min(m + 1, r0 + 8000)
+            ref[r0:r1].addcmul_(e[r0:r1, None], rowr[None, :])
+        ref[r] = e[r] * rowr
+        ref[:, j] = 0.0
+        ref[r, j] = 1.0
+        f32 = False
+    # compare by row blocks (a full-size temporary would be another 37 GB)
+    worst = 0.0
+    for r0 in range(0, m + 1, 8000):
+        r1 = min(m + 1, r0 + 8000)
+        diff = (T[r0:r1, :n + 1] - ref[r0:r1, :n + 1]).abs() / ref[r0:r1, :n + 1].abs().clamp_min(1.0)
+        worst = max(worst, float(diff.max()))
+    assert worst <= 1e-12, worst
+    # the last rows / columns (offsets > 2^32) were really written
+    assert float((T[m, :n] - ref[m, :n]).abs().max()) <= 1e-12 and bool((T[:, log[-1][1]] != 0).sum() == 1)
