@@ -57,6 +57,18 @@ def gen_dual(m, n, seed):
     return c, A, b, basis
 
 
+def gen_primal_degenerate(m, n, seed):
+    """Small-integer data with zeros in b: ties in the ratio test (degenerate pivots) and equal reduced costs, the
+    cases where "first index" tie-breaking (primal_solvers.py:137, :166) decides the pivot sequence."""
+    rng = np.random.default_rng(seed)
+    k = n - m
+    G = rng.integers(0, 3, (m, k)).astype(float)
+    A = np.hstack([G, np.eye(m)])
+    b = rng.integers(0, 3, m).astype(float)
+    c = np.concatenate([-rng.integers(0, 3, k).astype(float), np.zeros(m)])
+    return c, A, b, np.arange(k, n)
+
+
 def gen_box(m, n, seed):
     """Box-bounded LP for BoundedVariablePrimalSimplexSolver (reference limit: m <= 170)."""
     rng = np.random.default_rng(seed)

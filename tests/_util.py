@@ -14,7 +14,8 @@ _spec = importlib.util.spec_from_file_location("lpx_problems", os.path.join(ROOT
 gen = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gen)
 
-GENERATORS = {"gen_primal": gen.gen_primal, "gen_dual": gen.gen_dual, "gen_box": gen.gen_box}
+GENERATORS = {"gen_primal": gen.gen_primal, "gen_dual": gen.gen_dual, "gen_box": gen.gen_box,
+              "gen_primal_degenerate": gen.gen_primal_degenerate}
 
 # north_star: objective and solution within 1e-9 relative in fp64
 RTOL = 1e-9

@@ -257,6 +257,23 @@ def random_cases(large):
     return out
 
 
+def degenerate_cases():
+    """Integer data with ties (degenerate pivots, equal reduced costs): first-index tie-breaking decides the sequence.
+    Primal only: on the dual counterpart (integer data, b <= 0) the reference's tolerance-free dual ratio test pivots on
+    rounding noise -- its pivot sequences there depend on BLAS summation order and 3 of 9 of its "optimal" answers
+    disagree with HiGHS, so they cannot serve as golden vectors."""
+    out = []
+    PR = primal_solvers.PrimalRevisedSimplexSolver
+    for m, n in ((4, 8), (8, 16), (12, 30), (16, 32), (32, 64), (64, 128)):
+        for seed in range(3):
+            c, A, b, basis = gen.gen_primal_degenerate(m, n, seed)
+            r = run_base(PR, c, A, b, basis, 5000)
+            out.append(dict(gen="gen_primal_degenerate", solver="PrimalRevisedSimplexSolver", m=m, n=n, seed=seed,
+                            maxiters=5000, ref=r))
+            print(f"  gen_primal_degenerate m={m} seed={seed}: {len(r['pivots'])} pivots, exc={r['exception']}", flush=True)
+    return out
+
+
 def bounded_cases():
     out = []
     for m in (16, 64, 128, 170):
@@ -307,6 +324,7 @@ def main():
     dump("bounded.json", bounded_cases)
     dump("primal_dual.json", primal_dual_cases)
     dump("random.json", lambda: random_cases(False))
+    dump("degenerate.json", degenerate_cases)
     if args.large:
         dump("random_large.json", lambda: random_cases(True)[-3:])
 

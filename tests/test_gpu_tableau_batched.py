@@ -6,7 +6,7 @@ from tests._util import assert_close, case_id, gen, load, problem_of
 
 pytestmark = pytest.mark.gpu
 
-PRIMAL = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json")
+PRIMAL = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json") + load("degenerate.json")
           if cs["solver"] == "PrimalRevisedSimplexSolver" and not cs["ref"]["exception"]]
 
 
