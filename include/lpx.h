@@ -239,6 +239,14 @@ int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A
                              int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
                              void *stream);
 
+/* Inequality form: min c.x s.t. G x <= h, x >= 0 with h >= 0 (caller's check), i.e. the standard form [G | I] that
+ * preprocessing.py:17-69 builds on the host, started from the slack basis.  The identity block and the zero slack costs
+ * never exist in HBM: the kernels generate them.  G is batch x m x k, c batch x k, x batch x (k+m) (slacks included),
+ * basis batch x m (output only).  Same kernels, same bits as lpx_batched_primal_solve on the materialised problem. */
+int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
+                                  int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
+                                  int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
+
 /* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
 /* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:
  * _update_inv_basis_matrix / _update_bfs, primal_solvers.py:247-253.  rowr_scratch: >= ld doubles. */

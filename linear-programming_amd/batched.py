@@ -14,6 +14,37 @@ from .exceptions import BasisIsPrimalInfeasibleError
 
 
 class BatchedPrimalSolver:
+    ineq_k = 0  # > 0: built by from_inequalities (A holds only G)
+
+    @classmethod
+    def from_inequalities(cls, c, G, h, log_cap=0):
+        """``min c.x  s.t.  G x <= h, x >= 0`` with ``h >= 0``, batch-major (B, k), (B, m, k), (B, m): the standard form
+        ``[G | I]`` of preprocessing.py:17-69 started from the slack basis, without ever building the identity block on
+        the host or in HBM (``lpx_batched_primal_solve_ineq``).  Results carry all k+m variables, slacks last."""
+        torch = torch_cuda()
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        G32 = np.ascontiguousarray(np.asarray(G).astype(np.float32))
+        h32 = np.asarray(h).astype(np.float32)
+        if np.any(h32 < 0):
+            raise BasisIsPrimalInfeasibleError  # the slack basis is the start: x_B = h
+        self.B, self.m, k = G32.shape
+        self.n, self.ineq_k = k + self.m, k
+        self.Binv0 = None
+        self.A, self.b, self.c = to_device(G32), to_device(h32), to_device(np.asarray(c).astype(np.float32))
+        self.basis = torch.zeros((self.B, self.m), dtype=torch.int64, device="cuda")
+        self._alloc_outputs(torch, log_cap)
+        return self
+
+    def _alloc_outputs(self, torch, log_cap):
+        self.x = torch.zeros((self.B, self.n), dtype=torch.float64, device="cuda")
+        self.cost = torch.zeros(self.B, dtype=torch.float64, device="cuda")
+        self.status = torch.zeros(self.B, dtype=torch.int32, device="cuda")
+        self.iters = torch.zeros(self.B, dtype=torch.int64, device="cuda")
+        self.pivots = torch.zeros(self.B, dtype=torch.int64, device="cuda")
+        self.log_cap = int(log_cap)
+        self.log = torch.zeros((self.B, max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
+
     def __init__(self, c, A, b, basis, log_cap=0):
         torch = torch_cuda()
         self.lib = _lib.load()
@@ -39,16 +70,17 @@ class BatchedPrimalSolver:
             raise BasisIsPrimalInfeasibleError
         self.A, self.b, self.c = to_device(A32), to_device(b32), to_device(c32)
         self.basis = to_device(basis)
-        self.x = torch.zeros((self.B, self.n), dtype=torch.float64, device="cuda")
-        self.cost = torch.zeros(self.B, dtype=torch.float64, device="cuda")
-        self.status = torch.zeros(self.B, dtype=torch.int32, device="cuda")
-        self.iters = torch.zeros(self.B, dtype=torch.int64, device="cuda")
-        self.pivots = torch.zeros(self.B, dtype=torch.int64, device="cuda")
-        self.log_cap = int(log_cap)
-        self.log = torch.zeros((self.B, max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
+        self._alloc_outputs(torch, log_cap)
 
     def enqueue(self, maxiters):
         """Launch the batch (asynchronous).  NOTE: a solve always starts from the constructor's basis."""
+        if self.ineq_k:
+            _lib.check(self.lib.lpx_batched_primal_solve_ineq(
+                self.B, self.m, self.ineq_k, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),
+                self.x.data_ptr(), self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
+                self.pivots.data_ptr(), int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap,
+                stream_ptr()))
+            return
         _lib.check(self.lib.lpx_batched_primal_solve(
             self.B, self.m, self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(),
             None if self.Binv0 is None else self.Binv0.data_ptr(), self.basis.data_ptr(), self.x.data_ptr(),
@@ -71,6 +103,32 @@ class BatchedPrimalSolver:
         p = self.pivots.cpu().numpy()
         lg = self.log.cpu().numpy()
         return [lg[i, : min(int(p[i]), self.log_cap)] for i in range(self.B)]
+
+
+def solve_many(problems, maxiters=100):
+    """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
+    launches of different shapes run on separate streams, results come back in input order."""
+    torch = torch_cuda()
+    groups = {}
+    for idx, (c, A, b, basis) in enumerate(problems):
+        groups.setdefault(np.asarray(A).shape, []).append(idx)
+    solvers = []
+    main = torch.cuda.current_stream()
+    for shape, idxs in groups.items():
+        st = torch.cuda.Stream()
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            s = BatchedPrimalSolver(*[np.stack([np.asarray(problems[i][k]) for i in idxs]) for k in range(4)])
+            s.enqueue(maxiters)
+        solvers.append((idxs, s, st))
+    out = [None] * len(problems)
+    for idxs, s, st in solvers:
+        st.synchronize()
+        r = s.results()
+        for pos, i in enumerate(idxs):
+            out[i] = LinProgResult(x=r["x"][pos], basis=r["basis"][pos], cost=np.float64(r["cost"][pos]),
+                                   iters=int(r["iters"][pos]), optimum=bool(r["status"][pos] == _lib.OPTIMAL))
+    return out
 
 
 def shard(count, rank, world):

@@ -48,6 +48,8 @@ struct BatchArgs {
     int64_t maxiters;
     int64_t *log;
     int64_t log_cap;
+    int64_t kstruct; // 0: A is m x n.  > 0: inequality form G x <= h -- A holds only G (m x kstruct), c only its kstruct
+                     // costs; columns kstruct..n-1 are the slack identity with zero cost and form the starting basis
 };
 
 struct BatchLds {
@@ -171,10 +173,19 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
     const int ldb = (int)L.ldb;
 
     // ---- load the LP into LDS
-    const float *gA = a.A + lp * (int64_t)m * n;
-    for (int idx = t; idx < m * n; idx += LPX_BLOCK) L.A[idx] = gA[idx];
+    const int ks = (int)a.kstruct;
+    if (ks == 0) {
+        const float *gA = a.A + lp * (int64_t)m * n;
+        for (int idx = t; idx < m * n; idx += LPX_BLOCK) L.A[idx] = gA[idx];
+    } else { // [G | I] assembled here: the identity never exists in HBM
+        const float *gG = a.A + lp * (int64_t)m * ks;
+        for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
+            const int row = idx / n, col = idx - row * n;
+            L.A[idx] = col < ks ? gG[row * ks + col] : (col - ks == row ? 1.f : 0.f);
+        }
+    }
     for (int idx = t; idx < n; idx += LPX_BLOCK) {
-        L.c[idx] = a.c[lp * n + idx];
+        L.c[idx] = ks == 0 ? a.c[lp * n + idx] : (idx < ks ? a.c[lp * ks + idx] : 0.f);
         L.vstate[idx] = LPX_VS_LOWER;
     }
     {
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
             if (k >= m) { k -= m; i += 1; }
         }
     }
-    if (t < m) L.basis[t] = (int)a.basis[lp * m + t];
+    if (t < m) L.basis[t] = ks == 0 ? (int)a.basis[lp * m + t] : ks + t;
     __syncthreads();
     if (t < m) {
         L.vstate[L.basis[t]] = LPX_VS_BASIC;
@@ -429,13 +440,18 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
     ColT Ac[CPL][64];
     float ct[CPL];
     {
-        const float *gA = a.A + lp * (int64_t)m * n;
+        const int ks = (int)a.kstruct, na = ks == 0 ? n : ks; // stored columns of A (inequality form: G only)
+        const float *gA = a.A + lp * (int64_t)m * na;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
-            const int col = t + 64 * q, cc = col < n ? col : n - 1;
+            const int col = t + 64 * q, cc = col < na ? col : na - 1;
+            const bool slack = ks != 0 && col >= ks; // unit column, never read from HBM
 #pragma unroll
-            for (int k = 0; k < 64; ++k) Ac[q][k] = (ColT)gA[(int64_t)(k < m ? k : m - 1) * n + cc];
-            ct[q] = a.c[lp * n + cc];
+            for (int k = 0; k < 64; ++k) {
+                const float v = gA[(int64_t)(k < m ? k : m - 1) * na + cc];
+                Ac[q][k] = (ColT)(slack ? (k == col - ks ? 1.f : 0.f) : v);
+            }
+            ct[q] = slack ? 0.f : a.c[lp * na + cc];
             S.cf[col] = col < n ? ct[q] : 0.f;
             S.vst[col] = 0;
         }
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
     S.negz[t] = -0.0;
     int bas = 0;
     if (has_row) {
-        bas = (int)a.basis[lp * m + t];
+        bas = a.kstruct == 0 ? (int)a.basis[lp * m + t] : (int)a.kstruct + t;
         S.y[t] = (double)a.b[lp * m + t];
     }
     __syncthreads();
@@ -676,10 +692,9 @@ static int batched_wave_launch(const BatchArgs &a, hipStream_t stream)
     return a.m % 8 ? batched_wave_launch2<CPL, ColT, true>(a, stream) : batched_wave_launch2<CPL, ColT, false>(a, stream);
 }
 
-extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
-                                        const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
-                                        int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
-                                        void *stream)
+static int batched_solve(int64_t batch, int64_t m, int64_t n, int64_t kstruct, const float *A, const float *b, const float *c,
+                         const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                         int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap, void *stream)
 {
     LPX_REQUIRE(batch > 0 && m > 0 && n > 0 && maxiters >= 0, "bad sizes");
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
@@ -688,7 +703,7 @@ extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, con
         lpx_set_error("lpx_batched_primal_solve: m and n must be <= %d (one lane per row/column)", LPX_BLOCK);
         return LPX_E_SIZE;
     }
-    BatchArgs a{batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
+    BatchArgs a{batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, kstruct};
     // LPX_BATCH_KERNEL = wave | generic pins one of the two kernels (tests, diagnostics); both produce the same bits.
     // Default: one wave per LP whenever the rows fit a wave.
     const char *pin = getenv("LPX_BATCH_KERNEL");
@@ -715,4 +730,20 @@ extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, con
     hipLaunchKernelGGL(k_batched_primal, dim3((unsigned)batch), dim3(LPX_BLOCK), (size_t)bytes, (hipStream_t)stream, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
+}
+
+extern "C" int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                                        const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                                        int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
+                                        void *stream)
+{
+    return batched_solve(batch, m, n, 0, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, stream);
+}
+
+extern "C" int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
+                                             int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                                             int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap, void *stream)
+{
+    LPX_REQUIRE(k > 0, "no structural columns");
+    return batched_solve(batch, m, k + m, k, G, h, c, nullptr, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, stream);
 }

@@ -230,3 +230,37 @@ def test_dual_tableau_larger_vs_oracle(m, n, seed):
     assert res.iters == ro.iters
     assert_close(res.x, ro.x, "x")
     assert_close(res.cost, ro.cost, "cost")
+
+
+@pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 100), (80, 120)])
+def test_batched_inequality_form_equals_materialised_problem(m, k):
+    """lpx_batched_primal_solve_ineq (G x <= h: slack identity generated in the kernel) returns the same bits as the
+    standard-form entry point on [G | I] and as the oracle; both kernels (m = 80 takes the generic one)."""
+    from linprog_amd.batched import BatchedPrimalSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_primal(m, k + m, 40 + s) for s in range(4)]
+    c = np.stack([p[0] for p in probs]); A = np.stack([p[1] for p in probs]); b = np.stack([p[2] for p in probs])
+    basis = np.stack([p[3] for p in probs])
+    full = BatchedPrimalSolver(c, A, b, basis, log_cap=2048)
+    rf = full.solve(100000)
+    ineq = BatchedPrimalSolver.from_inequalities(c[:, :k], A[:, :, :k], b, log_cap=2048)
+    ri = ineq.solve(100000)
+    for i, p in enumerate(probs):
+        o = O.OracleRevised(*p, log_cap=2048).solve(100000)
+        assert ineq.pivot_logs()[i].tolist() == full.pivot_logs()[i].tolist() == o.log.tolist()
+        assert np.array_equal(ri[i].x, rf[i].x) and np.array_equal(ri[i].x, o.x)
+        assert ri[i].cost == rf[i].cost == o.cost and ri[i].iters == o.iters
+        assert ri[i].basis.tolist() == o.basis.tolist()
+
+
+def test_solve_many_mixed_shapes():
+    from linprog_amd.batched import solve_many
+    from oracle import oracle as O
+
+    shapes = [(8, 16), (64, 128), (8, 16), (24, 50), (64, 128), (80, 170)]
+    probs = [gen.gen_primal(m, n, 70 + i) for i, (m, n) in enumerate(shapes)]
+    res = solve_many(probs, 100000)
+    for p, r in zip(probs, res):
+        o = O.OracleRevised(*p, log_cap=4).solve(100000)
+        assert r.optimum and r.iters == o.iters and np.array_equal(r.x, o.x) and r.cost == o.cost
