@@ -156,3 +156,17 @@ def test_dgemm_mfma_vs_numpy(env, M, N, K, transa):
     rc = lib.lpx_dgemm(transa, M, N, K, 1.0, dA.data_ptr(), As.shape[1], dB.data_ptr(), N, 0.0, None, 0, 0.0, dD.data_ptr(), N, st)
     assert rc == 0
     assert np.max(np.abs(dD.cpu().numpy() - A @ B)) <= 1e-13 * K * 16
+
+
+def test_plain_c_client_of_the_abi():
+    """examples/c_abi_demo (built by __graft_entry__.build() with gcc against include/lpx.h and liblpx.so): the C ABI used
+    without Python or PyTorch -- one LP through lpx_revised_iterate, four through lpx_batched_primal_solve_ineq."""
+    import os
+    import subprocess
+
+    from tests._util import ROOT
+
+    exe = os.path.join(ROOT, "examples", "c_abi_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c abi demo ok" in r.stdout, r.stdout + r.stderr
