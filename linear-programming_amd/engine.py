@@ -74,9 +74,13 @@ class RevisedEngine:
         return self.host_ctrl
 
     # ------------------------------------------------------------------ loop
+    #: opt-in: refine B^-1 (lpx_revised_refine) every this many pivots inside run(); None = never (the reference's loop)
+    refine_every = None
+
     def run(self, kind, maxiters):
         """One ``solve(maxiters)`` call of the reference: returns the control block after the loop ended."""
         st = stream_ptr()
+        last_refine = None
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         left = int(maxiters)
         ctrl = None
@@ -91,6 +95,12 @@ class RevisedEngine:
             ctrl = self.read_ctrl()
             if ctrl.status != _lib.RUNNING:
                 break
+            if self.refine_every and not self.naive:
+                if last_refine is None:
+                    last_refine = int(ctrl.pivots) - int(ctrl.counter)
+                if int(ctrl.pivots) - last_refine >= int(self.refine_every):
+                    self.refine(steps=1, update_xB=kind != _lib.KIND_BOUNDED)
+                    last_refine = int(ctrl.pivots)
         if ctrl is None:
             ctrl = self.read_ctrl()
         return ctrl

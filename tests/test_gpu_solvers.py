@@ -298,3 +298,21 @@ def test_primal_dual_warm_start_same_optimum_fewer_pivots(m, n, seed):
     assert abs(rw.cost - ref.fun) <= 1e-8 * max(1.0, abs(ref.fun))
     assert 0 < warm.inner_pivots <= cold.inner_pivots
     print(f"inner pivots cold {cold.inner_pivots} warm {warm.inner_pivots}, outer {rc.iters} / {rw.iters}")
+
+
+def test_refine_every_keeps_a_long_run_exact():
+    """Opt-in periodic refinement inside solve() (engine.refine_every): the full Bland solve of gen_primal(256, 512, 0)
+    (3470 pivots in the reference) still ends on the reference's optimum, and the final inverse is exact to 1e-12."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+
+    cs = [c for c in load("random_large.json") if c["m"] == 256][0]
+    c, A, b, basis = problem_of(cs)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    s._engine.refine_every = 400
+    res = s.solve(100000)
+    assert res.optimum
+    assert abs(res.cost - cs["ref"]["cost"]) <= 1e-9 * max(1.0, abs(cs["ref"]["cost"]))
+    assert sorted(res.basis.tolist()) == sorted(cs["ref"]["basis"])
+    eng = s._engine
+    Bm = np.asarray(A, dtype=np.float32).astype(np.float64)[:, eng.host_basis()]
+    assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(256))) < 1e-11
