@@ -239,6 +239,13 @@ int lpx_batched_primal_solve(int64_t batch, int64_t m, int64_t n, const float *A
                              int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
                              void *stream);
 
+/* DualRevisedSimplexSolver(c, A, b, basis).solve(maxiters) (dual_solvers.py:82-120) per LP: same arguments; the
+ * starting bases must be dual feasible (dual_solvers.py:14-16, caller's check).  status: LPX_OPTIMAL, LPX_RUNNING
+ * (maxiters hit) or LPX_DUAL_UNBOUNDED.  One wave per LP: m <= 64, n <= 256 (LPX_E_SIZE otherwise). */
+int lpx_batched_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                           const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                           int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
+                           void *stream);
 /* Inequality form: min c.x s.t. G x <= h, x >= 0 with h >= 0 (caller's check), i.e. the standard form [G | I] that
  * preprocessing.py:17-69 builds on the host, started from the slack basis.  The identity block and the zero slack costs
  * never exist in HBM: the kernels generate them.  G is batch x m x k, c batch x k, x batch x (k+m) (slacks included),

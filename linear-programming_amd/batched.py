@@ -10,11 +10,12 @@ import numpy as np
 from . import _lib
 from .data_classes import LinProgResult
 from .device import stream_ptr, to_device, torch_cuda
-from .exceptions import BasisIsPrimalInfeasibleError
+from .exceptions import BasisIsDualInfeasibleError, BasisIsPrimalInfeasibleError
 
 
 class BatchedPrimalSolver:
     ineq_k = 0  # > 0: built by from_inequalities (A holds only G)
+    _DUAL = False
 
     @classmethod
     def from_inequalities(cls, c, G, h, log_cap=0):
@@ -66,7 +67,12 @@ class BatchedPrimalSolver:
             inv = np.linalg.inv(Bmat)
             self.Binv0 = to_device(np.ascontiguousarray(inv.astype(np.float32)))
             bfs = np.einsum("bij,bj->bi", inv, b32)
-        if not np.all(bfs >= 0.0):
+        if self._DUAL:
+            inv = np.broadcast_to(eye, Bmat.shape) if self.Binv0 is None else inv
+            cB = np.take_along_axis(c32, basis, axis=1)
+            if not np.all(np.einsum("bi,bik,bkj->bj", cB, inv, A32) <= c32):  # dual_solvers.py:14-16, per LP
+                raise BasisIsDualInfeasibleError
+        elif not np.all(bfs >= 0.0):
             raise BasisIsPrimalInfeasibleError
         self.A, self.b, self.c = to_device(A32), to_device(b32), to_device(c32)
         self.basis = to_device(basis)
@@ -81,11 +87,15 @@ class BatchedPrimalSolver:
                 self.pivots.data_ptr(), int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap,
                 stream_ptr()))
             return
-        _lib.check(self.lib.lpx_batched_primal_solve(
+        f = self.lib.lpx_batched_dual_solve if self._DUAL else self.lib.lpx_batched_primal_solve
+        _lib.check(f(
             self.B, self.m, self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(),
             None if self.Binv0 is None else self.Binv0.data_ptr(), self.basis.data_ptr(), self.x.data_ptr(),
             self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(), self.pivots.data_ptr(),
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
+
+    def _optimum(self, status):
+        return bool(status == _lib.OPTIMAL)
 
     def results(self):
         """Raw batch-major outputs of the last launch on the host (one synchronising copy each)."""
@@ -97,12 +107,23 @@ class BatchedPrimalSolver:
         self.raw = self.results()
         x, cost, basis, status, iters = (self.raw[k] for k in ("x", "cost", "basis", "status", "iters"))
         return [LinProgResult(x=x[i], basis=basis[i], cost=np.float64(cost[i]), iters=int(iters[i]),
-                              optimum=bool(status[i] == _lib.OPTIMAL)) for i in range(self.B)]
+                              optimum=self._optimum(status[i])) for i in range(self.B)]
 
     def pivot_logs(self):
         p = self.pivots.cpu().numpy()
         lg = self.log.cpu().numpy()
         return [lg[i, : min(int(p[i]), self.log_cap)] for i in range(self.B)]
+
+
+class BatchedDualSolver(BatchedPrimalSolver):
+    """``DualRevisedSimplexSolver(c, A, b, basis).solve(maxiters)`` per LP (dual_solvers.py:9-120): dual-feasible starting
+    bases (checked per LP, :14-16), ``optimum`` None until reached as in the reference; ``raw["status"]`` tells dual
+    unbounded LPs (``_lib.DUAL_UNBOUNDED``) apart -- a batch cannot raise per LP.  m <= 64, n <= 256."""
+
+    _DUAL = True
+
+    def _optimum(self, status):
+        return True if status == _lib.OPTIMAL else None
 
 
 def solve_many(problems, maxiters=100):

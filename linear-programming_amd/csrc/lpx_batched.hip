@@ -425,7 +425,9 @@ struct WaveBufRow {
 
 // CPL columns of A per lane, held as ColT (double: no conversion inside the rc chain; float when 4 columns per lane
 // would not fit the register file as doubles)
-template <int CPL, typename ColT, bool PARTIAL>
+// DUAL: DualRevisedSimplexSolver's loop (dual_solvers.py:82-120) on the same state -- leaving row = first x_B < 0, the dual
+// row B^-1[r,:] A accumulated beside the reduced costs in the same pass over A's registers, ratio test over the columns.
+template <int CPL, typename ColT, bool PARTIAL, bool DUAL>
 __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
 {
     constexpr int LDB = LPX_WAVE_LDB;
@@ -494,6 +496,14 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
                 for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(Ac[q][k]));
         }
         LPX_STAMP(7)
+        int r_dual = 0;
+        if constexpr (DUAL) { // dual_solvers.py:47-54: optimal iff min(x_B) >= 0 or |min| <= atol; leaving = first x_B < 0
+            if (__ballot(has_row && xB < -LPX_ATOL) == 0) {
+                status = LPX_OPTIMAL;
+                return false;
+            }
+            r_dual = __builtin_ctzll(__ballot(has_row && xB < 0.0));
+        }
         // ---- y_t = (c_B @ B^-1)_t (:64, first product): column t, i ascending
         {
             AccT acc = (AccT)0;
@@ -522,14 +532,18 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
         int j = 0x7FFFFFFF;
         bool open = false;
         {
-            AccT acc[CPL];
+            AccT acc[CPL], acr[CPL]; // reduced-cost sums; dual row sums (DUAL)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) acc[q] = (AccT)0;
+            for (int q = 0; q < CPL; ++q) acc[q] = acr[q] = (AccT)0;
+            const double *brow = S.Binv + r_dual * LDB; // row r of B^-1: broadcast operand of the dual row (:38)
             staged_blocks<WaveBuf8x2, PARTIAL>(
                 m,
                 [&](int kb, WaveBuf8x2 &B, int) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) B.a[u] = S.y[kb * 8 + u];
+                    for (int u = 0; u < 8; ++u) {
+                        B.a[u] = S.y[kb * 8 + u];
+                        if constexpr (DUAL) B.b[u] = brow[kb * 8 + u];
+                    }
                 },
                 [&](int kb, WaveBuf8x2 &B, int cnt) {
 #pragma unroll
@@ -538,19 +552,53 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
                             const AccT yk = (AccT)B.a[u];
 #pragma unroll
                             for (int q = 0; q < CPL; ++q) acc[q] = fma(yk, (AccT)Ac[q][kb * 8 + u], acc[q]);
+                            if constexpr (DUAL) {
+                                const AccT bk = (AccT)B.b[u];
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q) acr[q] = fma(bk, (AccT)Ac[q][kb * 8 + u], acr[q]);
+                            }
                         }
                     }
                 });
             LPX_STAMP(2)
+            if constexpr (!DUAL) {
 #pragma unroll
-            for (int q = CPL - 1; q >= 0; --q) {
-                double rc;
-                if constexpr (F32) rc = (double)(ct[q] - acc[q]);
-                else rc = (double)ct[q] - acc[q];
-                if (basic[q] || t + 64 * q >= n) rc = 0.0;
-                const unsigned long long neg = __ballot(rc < 0.0);
-                open = open || __ballot(rc < -LPX_ATOL) != 0;
-                if (neg) j = 64 * q + __builtin_ctzll(neg);
+                for (int q = CPL - 1; q >= 0; --q) {
+                    double rc;
+                    if constexpr (F32) rc = (double)(ct[q] - acc[q]);
+                    else rc = (double)ct[q] - acc[q];
+                    if (basic[q] || t + 64 * q >= n) rc = 0.0;
+                    const unsigned long long neg = __ballot(rc < 0.0);
+                    open = open || __ballot(rc < -LPX_ATOL) != 0;
+                    if (neg) j = 64 * q + __builtin_ctzll(neg);
+                }
+            } else {
+                // dual ratio test (dual_solvers.py:61-80): theta_j = (-rc_j)/row_j over row_j < 0, first argmin;
+                // min(row) >= 0, i.e. no candidate at all, is dual unboundedness (:41-44)
+                double th[CPL], best = LPX_INF;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    double rc;
+                    if constexpr (F32) rc = (double)(ct[q] - acc[q]);
+                    else rc = (double)ct[q] - acc[q];
+                    double row = (double)acr[q];
+                    if (basic[q] || t + 64 * q >= n) { rc = 0.0; row = 0.0; }
+                    th[q] = lpx_dsd(rc, row, F32);
+                    best = fmin(best, th[q]);
+                    any = any || __ballot(row < 0.0) != 0;
+                }
+                if (!any) {
+                    status = LPX_DUAL_UNBOUNDED;
+                    return false;
+                }
+                const double thmin = wave_min(best);
+#pragma unroll
+                for (int q = CPL - 1; q >= 0; --q) {
+                    const unsigned long long at = __ballot(th[q] == thmin);
+                    if (at) j = 64 * q + __builtin_ctzll(at);
+                }
+                open = true;
             }
         }
         LPX_STAMP(3)
@@ -586,15 +634,18 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
             di = has_row ? (double)acc : -LPX_INF;
         }
         // ---- ratios (:165), max(d) (:146), np.argmin (:166): the first lane holding the minimum ratio
-        const double th = has_row ? lpx_psd(xB, di, F32) : LPX_INF;
+        int r = r_dual;
         LPX_STAMP(4)
-        if (__ballot(di > 0.0) == 0) { // max(d) <= 0 (:144-147)
-            status = LPX_PRIMAL_UNBOUNDED;
-            return false;
+        if constexpr (!DUAL) {
+            const double th = has_row ? lpx_psd(xB, di, F32) : LPX_INF;
+            if (__ballot(di > 0.0) == 0) { // max(d) <= 0 (:144-147)
+                status = LPX_PRIMAL_UNBOUNDED;
+                return false;
+            }
+            const double thmin = wave_min(th);
+            const unsigned long long at = __ballot(th == thmin);
+            r = at ? __builtin_ctzll(at) : 0;
         }
-        const double thmin = wave_min(th);
-        const unsigned long long at = __ballot(th == thmin);
-        const int r = at ? __builtin_ctzll(at) : 0;
         LPX_STAMP(5)
         // ---- eta column (:236-244), bfs <- E @ bfs, bookkeeping (:261)
         const double dr = lane_bcast(di, r), xr = lane_bcast(xB, r);
@@ -675,21 +726,21 @@ __global__ __launch_bounds__(64) void k_batched_wave(BatchArgs a)
     }
 }
 
-template <int CPL, typename ColT, bool PARTIAL>
+template <int CPL, typename ColT, bool PARTIAL, bool DUAL>
 static int batched_wave_launch2(const BatchArgs &a, hipStream_t stream)
 {
     const int64_t bytes = wave_lds(a.m, CPL, nullptr).bytes;
     // per launch, not cached: the attribute belongs to the current device and a process may drive several
-    LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT, PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    LPX_HIP(hipFuncSetAttribute((const void *)k_batched_wave<CPL, ColT, PARTIAL, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)bytes));
-    hipLaunchKernelGGL((k_batched_wave<CPL, ColT, PARTIAL>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
+    hipLaunchKernelGGL((k_batched_wave<CPL, ColT, PARTIAL, DUAL>), dim3((unsigned)a.batch), dim3(64), (size_t)bytes, stream, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }
-template <int CPL, typename ColT>
+template <int CPL, typename ColT, bool DUAL = false>
 static int batched_wave_launch(const BatchArgs &a, hipStream_t stream)
 {
-    return a.m % 8 ? batched_wave_launch2<CPL, ColT, true>(a, stream) : batched_wave_launch2<CPL, ColT, false>(a, stream);
+    return a.m % 8 ? batched_wave_launch2<CPL, ColT, true, DUAL>(a, stream) : batched_wave_launch2<CPL, ColT, false, DUAL>(a, stream);
 }
 
 static int batched_solve(int64_t batch, int64_t m, int64_t n, int64_t kstruct, const float *A, const float *b, const float *c,
@@ -746,4 +797,24 @@ extern "C" int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k
 {
     LPX_REQUIRE(k > 0, "no structural columns");
     return batched_solve(batch, m, k + m, k, G, h, c, nullptr, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, stream);
+}
+
+// DualRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (dual_solvers.py:82-120): same arguments as the primal
+// entry point; the starting basis must be dual feasible (caller's check, dual_solvers.py:14-16).  One wave per LP only.
+extern "C" int lpx_batched_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                                      const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                                      int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap,
+                                      void *stream)
+{
+    LPX_REQUIRE(batch > 0 && m > 0 && n > 0 && maxiters >= 0, "bad sizes");
+    LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
+    LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
+    if (m > 64 || n > 256) {
+        lpx_set_error("lpx_batched_dual_solve: m <= 64 and n <= 256 (one wave per LP), not %lld x %lld", (long long)m, (long long)n);
+        return LPX_E_SIZE;
+    }
+    BatchArgs a{batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, 0};
+    if (n <= 64) return batched_wave_launch<1, double, true>(a, (hipStream_t)stream);
+    if (n <= 128) return batched_wave_launch<2, double, true>(a, (hipStream_t)stream);
+    return batched_wave_launch<4, float, true>(a, (hipStream_t)stream);
 }

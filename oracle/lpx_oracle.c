@@ -692,7 +692,7 @@ double lpo_expand_and_cost(const double *xB, const int64_t *basis, const float *
  * primal_solvers.py:176-263), one LP per OpenMP thread: the CPU side of SURVEY.md 8(d) config 3.  Slack or general
  * start: Binv0 = float32 B^-1 per LP or NULL for the identity; x_B = B^-1 b in float32 (:38), accumulated in index
  * order.  Outputs per LP: basis (in place), x (n), cost, status, iters (reference counter), pivots. */
-void lpo_primal_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+static void lpo_solve_batch(int dual, int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                             const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
                             int64_t *iters, int64_t *pivots, int64_t maxiters, int threads)
 {
@@ -730,7 +730,7 @@ void lpo_primal_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A,
             for (int64_t j = 0; j < n; ++j) vs[j] = VS_LOWER;
             for (int64_t i = 0; i < m; ++i) vs[s.basis[i]] = VS_BASIC;
             s.f32_phase = 1;
-            status[l] = lpo_primal_solve(&s, maxiters);
+            status[l] = dual ? lpo_dual_solve(&s, maxiters) : lpo_primal_solve(&s, maxiters);
             iters[l] = s.counter;
             pivots[l] = s.pivots;
             cost[l] = lpo_expand_and_cost(s.xB, s.basis, s.c, m, n, x + l * n);
@@ -738,6 +738,21 @@ void lpo_primal_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A,
         free(buf);
         free(vs);
     }
+}
+
+void lpo_primal_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                            const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status,
+                            int64_t *iters, int64_t *pivots, int64_t maxiters, int threads)
+{
+    lpo_solve_batch(0, batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, threads);
+}
+
+/* The same through lpo_dual_solve (DualRevisedSimplexSolver.solve, dual_solvers.py:82-120). */
+void lpo_dual_solve_batch(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                          const float *Binv0, int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                          int64_t *pivots, int64_t maxiters, int threads)
+{
+    lpo_solve_batch(1, batch, m, n, A, b, c, Binv0, basis, x, cost, status, iters, pivots, maxiters, threads);
 }
 
 int lpo_version(void) { return 1; }

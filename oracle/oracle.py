@@ -108,6 +108,8 @@ def lib():
         L.lpo_primal_solve_batch.argtypes = [C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, _fp, _ip, _dp, _dp, _sp, _ip,
                                              _ip, C.c_int64, C.c_int]
         L.lpo_primal_solve_batch.restype = None
+        L.lpo_dual_solve_batch.argtypes = L.lpo_primal_solve_batch.argtypes
+        L.lpo_dual_solve_batch.restype = None
         _lib = L
     return _lib
 
@@ -202,21 +204,35 @@ def expand_and_cost(xB, basis, c32, n):
     return x, cost
 
 
-def primal_solve_batch(c, A, b, basis, maxiters=100, threads=1):
-    """A batch of LPs of one shape (batch-major arrays, slack start: B = I) through lpo_primal_solve, one LP per
-    OpenMP thread.  Returns dict(x, basis, cost, status, iters, pivots)."""
-    A = np.ascontiguousarray(np.asarray(A).astype(np.float32))
-    b = np.ascontiguousarray(np.asarray(b).astype(np.float32))
+def solve_batch(c, A, b, basis, maxiters=100, threads=1, kind="primal"):
+    """A batch of LPs of one shape (batch-major arrays) through lpo_primal_solve / lpo_dual_solve, one LP per OpenMP
+    thread.  Inputs go through the reference's preprocessing per LP (float32, rows with b < 0 flipped,
+    preprocessing.py:6-15); a starting basis that is not the identity gets its float32 inverse (primal_solvers.py:37).
+    Returns dict(x, basis, cost, status, iters, pivots)."""
+    A = np.array(A).astype(np.float32)
+    b = np.array(b).astype(np.float32)
     c = np.ascontiguousarray(np.asarray(c).astype(np.float32))
+    neg = b < 0
+    A[neg] *= -1
+    b[neg] *= -1
+    A = np.ascontiguousarray(A)
     basis = np.ascontiguousarray(np.array(basis).astype(np.int64))
     B, m, n = A.shape
+    Bm = np.take_along_axis(A, basis[:, None, :], axis=2)
+    inv0 = None
+    if not np.array_equal(Bm, np.broadcast_to(np.eye(m, dtype=np.float32), Bm.shape)):
+        inv0 = np.ascontiguousarray(np.linalg.inv(Bm).astype(np.float32))
     x, cost = np.empty((B, n)), np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters, pivots = np.empty(B, dtype=np.int64), np.empty(B, dtype=np.int64)
-    lib().lpo_primal_solve_batch(B, m, n, _p(A, _fp), _p(b, _fp), _p(c, _fp), None, _p(basis, _ip), _p(x, _dp),
-                                 _p(cost, _dp), _p(status, _sp), _p(iters, _ip), _p(pivots, _ip), int(maxiters),
-                                 int(threads))
+    f = lib().lpo_primal_solve_batch if kind == "primal" else lib().lpo_dual_solve_batch
+    f(B, m, n, _p(A, _fp), _p(b, _fp), _p(c, _fp), None if inv0 is None else _p(inv0, _fp), _p(basis, _ip), _p(x, _dp),
+      _p(cost, _dp), _p(status, _sp), _p(iters, _ip), _p(pivots, _ip), int(maxiters), int(threads))
     return dict(x=x, basis=basis, cost=cost, status=status, iters=iters, pivots=pivots)
+
+
+def primal_solve_batch(c, A, b, basis, maxiters=100, threads=1):
+    return solve_batch(c, A, b, basis, maxiters, threads, "primal")
 
 
 # ------------------------------------------------------------------------------------------------ solvers

@@ -264,3 +264,50 @@ def test_solve_many_mixed_shapes():
     for p, r in zip(probs, res):
         o = O.OracleRevised(*p, log_cap=4).solve(100000)
         assert r.optimum and r.iters == o.iters and np.array_equal(r.x, o.x) and r.cost == o.cost
+
+
+@pytest.mark.parametrize("m,n", [(8, 16), (13, 40), (32, 64), (37, 100), (64, 128), (64, 256), (60, 150)])
+def test_batched_dual_bit_identical_to_oracle(m, n):
+    """BatchedDualSolver (one wave per LP, dual mode of the wave kernel) against the oracle's dual loop: pivot logs, x,
+    cost, basis, iters and status bit for bit; whole and partial row blocks, 1 / 2 / 4 columns per lane."""
+    from linprog_amd.batched import BatchedDualSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_dual(m, n, 200 + s) for s in range(5)]
+    args = [np.stack([p[k] for p in probs]) for k in range(4)]
+    solver = BatchedDualSolver(*args, log_cap=2048)
+    res = solver.solve(100000)
+    for i, p in enumerate(probs):
+        o = O.OracleRevised(*p, kind="dual", log_cap=2048).solve(100000)
+        assert solver.pivot_logs()[i].tolist() == o.log.tolist()
+        assert res[i].iters == o.iters and res[i].optimum is (True if o.status == O.OPTIMAL else None)
+        assert np.array_equal(res[i].x, o.x) and res[i].cost == o.cost
+        assert res[i].basis.tolist() == o.basis.tolist()
+
+
+def test_batched_dual_reference_sequences_limits_and_errors():
+    """Goldens of DualRevisedSimplexSolver (m <= 64): the batched dual kernel takes the reference's pivots; a maxiters
+    hit leaves optimum None; dual unbounded LPs are flagged in status; a dual infeasible start raises."""
+    from linprog_amd import _lib, exceptions
+    from linprog_amd.batched import BatchedDualSolver
+
+    cases = [c for c in load("random.json") if c["solver"] == "DualRevisedSimplexSolver" and c.get("gen") == "gen_dual"
+             and c["m"] <= 64 and not c["ref"]["exception"]]
+    assert len(cases) >= 10
+    for cs in cases:
+        c, A, b, basis = problem_of(cs)
+        s = BatchedDualSolver(c[None], A[None], b[None], basis[None], log_cap=1024)
+        r = s.solve(cs["maxiters"])[0]
+        ref = cs["ref"]
+        assert s.pivot_logs()[0].tolist() == ref["pivots"]
+        assert r.iters == ref["iters"] and r.optimum == ref["optimum"] and r.basis.tolist() == ref["basis"]
+        assert_close(r.x, ref["x"], "x")
+        assert_close(r.cost, ref["cost"], "cost")
+    ub = [c for c in load("random.json") if c.get("gen") == "gen_dual_unbounded" and c["solver"] == "DualRevisedSimplexSolver"][0]
+    c, A, b, basis = problem_of(ub)
+    s = BatchedDualSolver(c[None], A[None], b[None], basis[None], log_cap=64)
+    s.solve(1000)
+    assert s.raw["status"][0] == _lib.DUAL_UNBOUNDED and s.pivot_logs()[0].tolist() == ub["ref"]["pivots"]
+    c, A, b, basis = gen.gen_primal(8, 16, 0)  # not dual feasible at the slack basis
+    with pytest.raises(exceptions.BasisIsDualInfeasibleError):
+        BatchedDualSolver(c[None], A[None], b[None], basis[None])

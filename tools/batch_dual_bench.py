@@ -1,0 +1,37 @@
+"""LPs/s of the batched dual kernel on 4096 x gen_dual(64, 128, seed): python tools/batch_dual_bench.py (GPU box)."""
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+import linprog_amd  # noqa: F401
+from linprog_amd import problems
+from linprog_amd.batched import BatchedDualSolver
+from oracle import oracle as O
+
+B = 4096
+probs = [problems.gen_dual(64, 128, s) for s in range(B)]
+args = [np.stack([p[k] for p in probs]) for k in range(4)]
+s = BatchedDualSolver(*args)
+basis0 = s.basis.clone()
+for _ in range(2):
+    s.basis.copy_(basis0)
+    s.enqueue(100000)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+reps = 20
+for _ in range(reps):
+    s.basis.copy_(basis0)
+    s.enqueue(100000)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+r = s.results()
+piv = int(r["pivots"].sum())
+print(f"GPU: {B / dt:.0f} LPs/s, {piv / dt:.3e} pivots/s, {dt * 1e3:.2f} ms per batch, all optimal: {bool((r['status'] == 1).all())}")
+t0 = time.perf_counter()
+o = O.solve_batch(*args, 100000, threads=16, kind="dual")
+dc = time.perf_counter() - t0
+same = all(np.array_equal(r[k], o[k]) for k in ("x", "cost", "basis", "iters"))
+print(f"oracle (16 threads): {B / dc:.0f} LPs/s; bit-identical to the GPU: {same}")
