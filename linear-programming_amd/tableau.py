@@ -20,6 +20,14 @@ from .exceptions import (BasisIsDualInfeasibleError, BasisIsPrimalInfeasibleErro
 from .preprocessing import ProblemPreprocessingUtils
 
 
+def row_alignment(cols):
+    """Row stride granularity (doubles) of a streamed fp64 matrix.  K1's workgroups each own 512 consecutive columns of
+    one row: with 4-KiB-aligned rows every such strip is one aligned 4 KiB block and the update streams at 6.3 TB/s
+    instead of 5.7 (tools/oop_test.hip: 40002 -> 5.73, 40016 -> 6.01, 40448 -> 6.30 TB/s on the 20001 x 40001 tableau).
+    Small matrices keep the padding small: 128-byte lines, then pairs."""
+    return 512 if cols >= 4096 else (16 if cols >= 128 else 2)
+
+
 def column_range(n, rank, world):
     """Global columns [j0, j1) owned by `rank` in an N-way column partition."""
     return n * rank // world, n * (rank + 1) // world
@@ -101,10 +109,12 @@ class TableauEngine:
 
     # ------------------------------------------------------------------ construction from a host problem
     @classmethod
-    def from_columns(cls, A_cols32, b32, c32_global, basis, col0, n_global, inv32=None, bfs32=None, ld_align=2, **kw):
+    def from_columns(cls, A_cols32, b32, c32_global, basis, col0, n_global, inv32=None, bfs32=None, ld_align=None, **kw):
         """Build the local slice from columns [col0, col0+n_local) of the float32 A (slack basis unless inv32)."""
         torch = torch_cuda()
         m, n_local = A_cols32.shape
+        if ld_align is None:
+            ld_align = row_alignment(n_local + 1)
         ld = roundup(n_local + 1, ld_align)
         T = torch.zeros((m + 1, ld), dtype=torch.float64, device="cuda")
         A_dev = torch.from_numpy(np.ascontiguousarray(A_cols32)).to("cuda")

@@ -3,6 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/oop_test.hip -o tools/oop_test && ./tools/oop_test
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double d2_t __attribute__((ext_vector_type(2)));
 template <int NT>
 __global__ __launch_bounds__(256) void k(const double *src, double *dst, const double *e, const double *rowr, long cols, long ld)
@@ -17,15 +18,16 @@ __global__ __launch_bounds__(256) void k(const double *src, double *dst, const d
     if (NT) __builtin_nontemporal_store(x, (d2_t *)(dst + row * ld + col));
     else *(d2_t *)(dst + row * ld + col) = x;
 }
-int main()
+int main(int argc, char **argv)
 {
-    const long rows = 20001, cols = 40001, ld = 40002;
+    const long rows = 20001, cols = 40001, ld = argc > 1 ? atol(argv[1]) : 40002; // row stride experiment: ld as argument
     double *T0, *T1, *e, *rowr;
     hipMalloc(&T0, rows * ld * 8); hipMalloc(&T1, rows * ld * 8); hipMalloc(&e, rows * 8); hipMalloc(&rowr, ld * 8);
     hipMemset(T0, 0, rows * ld * 8); hipMemset(T1, 0, rows * ld * 8); hipMemset(e, 0, rows * 8); hipMemset(rowr, 0, ld * 8);
     dim3 grid((unsigned)((cols + 511) / 512), (unsigned)rows);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const double bytes = 16.0 * rows * cols;
+    printf("ld = %ld doubles (row stride %ld B)\n", ld, ld * 8);
     for (int mode = 0; mode < 4; ++mode) {
         const bool oop = mode & 1, nt = mode & 2;
         float best = 1e9f, tot = 0;
