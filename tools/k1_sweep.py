@@ -1,6 +1,6 @@
 """Sweep the launch parameters of the rank-1 pivot-update kernel (K1) on the GPU box.
 
-    python tools/k1_sweep.py [rows cols]        (default 20001 x 40001, the BASELINE config-4 tableau)
+    python tools/k1_sweep.py [rows cols [ld]]   (default 20001 x 40001, the BASELINE config-4 tableau, 4-KiB-aligned rows)
 
 Prints achieved algorithmic GB/s (16 B per element) per variant, from HIP events around K1 only, and two
 torch reference points measured the same way (in-place add = read+write stream, clone = copy).
@@ -19,7 +19,7 @@ from linprog_amd import _lib  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20001
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 40001
-ld = cols + (cols % 2)
+ld = int(sys.argv[3]) if len(sys.argv) > 3 else -(-cols // 512) * 512
 L = _lib.load()
 M = torch.rand((rows, ld), dtype=torch.float64, device="cuda")
 e = (torch.rand(rows, dtype=torch.float64, device="cuda") - 0.5) * 1e-3

@@ -5,6 +5,30 @@
 #include <stdio.h>
 #include <stdlib.h>
 typedef double d2_t __attribute__((ext_vector_type(2)));
+// MAP: 0 = workgroups in address order (hardware deals consecutive ids round-robin to the 8 XCDs); 1 = every XCD streams
+// runs of 8 consecutive 4-KiB strips (32 KiB); 2 = every XCD owns one contiguous eighth of the matrix
+template <int NT, int MAP>
+__global__ __launch_bounds__(256) void kmap(const double *src, double *dst, const double *e, const double *rowr, long cols, long ld,
+                                           long strips, long total)
+{
+    long id = blockIdx.x;
+    if (MAP == 1) {
+        const long g = id / 64, w = id % 64;
+        id = g * 64 + (w % 8) * 8 + w / 8;
+    } else if (MAP == 2) {
+        id = (id % 8) * (total / 8) + id / 8;
+    }
+    if (id >= total) return;
+    const long row = id / strips, col = ((id % strips) * 256 + threadIdx.x) * 2;
+    if (col >= cols) return;
+    const d2_t pr = *(const d2_t *)(rowr + col);
+    const double ei = e[row];
+    d2_t x = NT ? __builtin_nontemporal_load((const d2_t *)(src + row * ld + col)) : *(const d2_t *)(src + row * ld + col);
+    x[0] = fma(ei, pr[0], x[0]);
+    x[1] = fma(ei, pr[1], x[1]);
+    if (NT) __builtin_nontemporal_store(x, (d2_t *)(dst + row * ld + col));
+    else *(d2_t *)(dst + row * ld + col) = x;
+}
 template <int NT>
 __global__ __launch_bounds__(256) void k(const double *src, double *dst, const double *e, const double *rowr, long cols, long ld)
 {
@@ -44,6 +68,23 @@ int main(int argc, char **argv)
         }
         printf("%-12s %-5s avg %.3f ms  %.2f TB/s   best %.3f ms  %.2f TB/s\n", oop ? "out-of-place" : "in-place", nt ? "nt" : "plain",
                tot / reps, bytes / (tot / reps) / 1e9, best, bytes / best / 1e9);
+    }
+    // workgroup -> XCD mapping variants (in place, non-temporal, 1-D grid)
+    const long strips = (cols + 511) / 512, total = ((strips * rows + 63) / 64) * 64;
+    for (int map = 0; map < 3; ++map) {
+        float tot = 0, best = 1e9f;
+        const int reps = 20;
+        for (int it = 0; it < reps + 3; ++it) {
+            hipEventRecord(a, 0);
+            if (map == 0) hipLaunchKernelGGL((kmap<1, 0>), dim3((unsigned)total), dim3(256), 0, 0, T0, T0, e, rowr, cols, ld, strips, strips * rows);
+            if (map == 1) hipLaunchKernelGGL((kmap<1, 1>), dim3((unsigned)total), dim3(256), 0, 0, T0, T0, e, rowr, cols, ld, strips, strips * rows);
+            if (map == 2) hipLaunchKernelGGL((kmap<1, 2>), dim3((unsigned)total), dim3(256), 0, 0, T0, T0, e, rowr, cols, ld, strips, (strips * rows / 8) * 8);
+            hipEventRecord(b, 0); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (it >= 3) { tot += ms; if (ms < best) best = ms; }
+        }
+        printf("map %d           avg %.3f ms  %.2f TB/s   best %.3f ms  %.2f TB/s\n", map, tot / reps, bytes / (tot / reps) / 1e9, best,
+               bytes / best / 1e9);
     }
     return 0;
 }
