@@ -27,7 +27,8 @@ class RevisedEngine:
         m, n = A32.shape
         self.m, self.n = m, n
         # B^-1 is the matrix K1 streams: 4-KiB-aligned rows once it is large (see tableau.row_alignment)
-        self.ldA, self.ldAt, self.ldB = roundup(n, 4), roundup(m, 4), roundup(m, 512 if m >= 4096 else (16 if m >= 128 else 2))
+        pad = lambda cols, unit: roundup(cols, 4096 // unit if cols * unit >= 32768 else (128 // unit if cols * unit >= 1024 else 16 // unit))
+        self.ldA, self.ldAt, self.ldB = pad(n, 4), pad(m, 4), pad(m, 8)
         self.A = to_device_2d(A32.astype(np.float32, copy=False), self.ldA, torch.float32)
         self.At = torch.zeros((n, self.ldAt), dtype=torch.float32, device="cuda")
         self.At[:, :m].copy_(self.A[:, :n].t())
