@@ -213,6 +213,7 @@ struct ColsumArgs {
     const double *ypart;
     int64_t ynch, yld;
     int lds_weights; // weights staged in dynamic LDS (rpc * 8 bytes)
+    int nt;          // matrix larger than the Infinity Cache: non-temporal loads (it is read once per launch)
 };
 
 template <typename AccT>
@@ -241,7 +242,21 @@ __device__ __forceinline__ AccT fin_sum(const double *part, int64_t nch, int64_t
     return s;
 }
 
-template <typename MatT, typename AccT, int V>
+// a matrix that does not fit the 256 MiB Infinity Cache next to the rest of an iteration is streamed past it
+// (LPX_STREAM_NT = 0 / 1 forces the choice)
+static inline int lpx_stream_nt(int64_t bytes)
+{
+    const int f = lpx_env_int("LPX_STREAM_NT", -1);
+    return f >= 0 ? (f != 0) : (bytes > ((int64_t)192 << 20));
+}
+
+template <bool NT, typename VecT>
+__device__ __forceinline__ VecT lpx_stream_load(const VecT *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+template <typename MatT, typename AccT, int V, bool NT>
 __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
 {
     typedef MatT vec_t __attribute__((ext_vector_type(V)));
@@ -267,10 +282,10 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
     const MatT *p = (const MatT *)a.M + row0 * a.ld + col;
     int64_t i = row0;
     for (; i + 4 <= row1; i += 4) {
-        const vec_t x0 = *(const vec_t *)p;
-        const vec_t x1 = *(const vec_t *)(p + a.ld);
-        const vec_t x2 = *(const vec_t *)(p + 2 * a.ld);
-        const vec_t x3 = *(const vec_t *)(p + 3 * a.ld);
+        const vec_t x0 = lpx_stream_load<NT>((const vec_t *)p);
+        const vec_t x1 = lpx_stream_load<NT>((const vec_t *)(p + a.ld));
+        const vec_t x2 = lpx_stream_load<NT>((const vec_t *)(p + 2 * a.ld));
+        const vec_t x3 = lpx_stream_load<NT>((const vec_t *)(p + 3 * a.ld));
         AccT w0, w1, w2, w3;
         if (lds_w) {
             w0 = wl[i - row0]; w1 = wl[i + 1 - row0]; w2 = wl[i + 2 - row0]; w3 = wl[i + 3 - row0];
@@ -288,7 +303,7 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
         p += 4 * a.ld;
     }
     for (; i < row1; ++i) {
-        const vec_t x0 = *(const vec_t *)p;
+        const vec_t x0 = lpx_stream_load<NT>((const vec_t *)p);
         const AccT w0 = lds_w ? wl[i - row0] : colsum_weight<AccT>(a, i, r);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = fma(w0, (AccT)x0[v], acc[v]);
@@ -304,8 +319,9 @@ template <typename MatT, int V>
 __global__ __launch_bounds__(LPX_BLOCK) void k_colsum(ColsumArgs a)
 {
     if (a.ctrl->status != LPX_RUNNING) return;
-    if (a.ctrl->f32_phase) colsum_body<MatT, float, V>(a);
-    else colsum_body<MatT, double, V>(a);
+    if (a.ctrl->f32_phase) colsum_body<MatT, float, V, false>(a); // first iteration only
+    else if (a.nt) colsum_body<MatT, double, V, true>(a);
+    else colsum_body<MatT, double, V, false>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -436,18 +452,19 @@ struct DirArgs {
     int64_t forced_j;
     int64_t nprice; // number of pricing partials
     int rpw;        // rows per wave
+    int nt;         // B^-1 larger than the Infinity Cache: non-temporal loads
     Partials price, ratio;
     double *d;
 };
 
-template <typename AccT>
+template <typename AccT, bool NT = false>
 __device__ __forceinline__ double dir_row(const double *Bi, const float *aj, int64_t m)
 {
     const int lane = threadIdx.x & 63;
     AccT acc0 = (AccT)0, acc1 = (AccT)0;
     const int64_t m2 = m & ~(int64_t)1;
     for (int64_t k = lane * 2; k < m2; k += 128) {
-        const d2_t bv = *(const d2_t *)(Bi + k);
+        const d2_t bv = lpx_stream_load<NT>((const d2_t *)(Bi + k));
         const f2_t av = *(const f2_t *)(aj + k);
         acc0 = fma((AccT)bv.x, (AccT)av.x, acc0);
         acc1 = fma((AccT)bv.y, (AccT)av.y, acc1);
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_direction(DirArgs a)
         const int64_t i = rbase + q;
         if (i >= m) break; // wave-uniform
         const double *Bi = a.s.Binv + i * a.s.ldB;
-        const double di = f32 ? dir_row<float>(Bi, aj, m) : dir_row<double>(Bi, aj, m);
+        const double di = f32 ? dir_row<float>(Bi, aj, m) : (a.nt ? dir_row<double, true>(Bi, aj, m) : dir_row<double>(Bi, aj, m));
         if (lane == 0) a.d[i] = di;
         if (a.kind == DIR_PRIMAL) {
             const double th = lpx_psd(a.s.xB[i], di, f32);
@@ -856,6 +873,7 @@ static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_
     a.part = w.ypart; a.ldp = w.ldyp; a.ctrl = s->ctrl;
     const size_t lds = colsum_lds_bytes(w.py.rpc);
     a.lds_weights = lds != 0;
+    a.nt = lpx_stream_nt(8 * s->m * s->ldB);
     hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), lds, st, a);
 }
 static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
@@ -867,6 +885,7 @@ static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode,
     a.ypart = w.ypart; a.ynch = w.py.nch; a.yld = w.ldyp;
     const size_t lds = colsum_lds_bytes(w.pa.rpc);
     a.lds_weights = lds != 0;
+    a.nt = lpx_stream_nt(4 * s->m * s->ldA);
     hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), lds, st, a);
 }
 static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, double *rc_out, hipStream_t st)
@@ -897,6 +916,7 @@ static void launch_direction(const lpx_revised *s, const RevisedWs &w, int kind,
     DirArgs a{};
     a.s = *s; a.kind = kind; a.forced_j = forced_j; a.nprice = lpx_cdiv(s->n, LPX_BLOCK);
     a.rpw = dir_rows_per_wave(s->m);
+    a.nt = lpx_stream_nt(8 * s->m * s->ldB);
     a.price = w.price; a.ratio = w.ratio; a.d = w.d;
     hipLaunchKernelGGL(k_direction, dim3((unsigned)lpx_cdiv(s->m, (int64_t)a.rpw * LPX_WAVES)), dim3(LPX_BLOCK), 0, st, a);
 }
