@@ -39,8 +39,27 @@ def parse():
     return ap.parse_args()
 
 
+_JSON_FD = None
+
+
+def emit(out):
+    """The one JSON line, on the process's original stdout."""
+    line = (json.dumps(out) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.buffer.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
+    global _JSON_FD
     args = parse()
+    # RCCL writes its version banner to stdout from C when the first communicator is created: everything but the
+    # JSON line goes to stderr
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -178,7 +197,7 @@ def main():
         chk = cpu_baseline(args, m, n, full[0], full[1], full[2], full[3], solver, kc=kc)
         out["parity"] = None if chk is None else chk["parity"]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if group is not None:
         dist.barrier()  # rank 0's oracle check is done: nobody tears the communicator down under a busy peer
         dist.destroy_process_group()
@@ -269,7 +288,7 @@ def bench_revised(args):
                         "traffic": None, "avg_launch_ms": k1_s * 1e3,
                         "whole_iteration_GBs": iter_bytes * K / dt / 1e9},
            "cpu_baseline": cpu}
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def bench_config5(args):
@@ -330,7 +349,7 @@ def bench_config5(args):
            "cpu_baseline": {"value": 1.0 / cpu_t, "unit": "sets/s", "cores": 1, "kind": "port",
                             "sample": "the same set once through the oracle (C, single thread, Python constructors included)",
                             "parity": "iters equal and cost within 1e-9 for every problem of the set"}}
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def bench_batch(args, rank, world, group):
@@ -420,7 +439,7 @@ def bench_batch(args, rank, world, group):
         else:
             out["parity"] = f"x, cost, basis and iters of rank 0's {per_gpu} LPs bit-identical to the oracle's"
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -227,6 +227,21 @@ int lpx_revised_refine(const lpx_revised *s, int64_t steps, int update_xB, void 
 int lpx_dgemm(int transa, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
               int64_t ldb, double beta, const double *C, int64_t ldc, double gamma, double *D, int64_t ldd, void *stream);
 
+/* Opt-in reinversion in fp64.  Reference analogue: np.linalg.inv(A[:, basis]),
+ * primal_solvers.py:92-94 (the naive solvers' per-pivot reinversion; the revised solvers never re-invert).
+ * Blocked Gauss-Jordan with partial pivoting, 64 columns per block; the m x m x 64 trailing updates are fp64 MFMA
+ * GEMMs and carry all 2 m^3 flop.  info: one device int64 -- 0, or 1 + the first column whose pivot candidates are
+ * all below m * eps * max|A| (numpy raises LinAlgError("Singular matrix") for exact zeros; the output is then not an
+ * inverse).
+ *   lpx_dinverse:             Ainv = A^-1, row-major m x m, Ainv may be A
+ *   lpx_revised_reinvert_f64: s->Binv = inv(A[:, basis]) from scratch, x_B = B^-1 b when update_xB != 0; clears the
+ *                             float32 phase.  Never called by solve(). */
+int64_t lpx_invert_workspace_bytes(int64_t m);
+int lpx_dinverse(int64_t m, const double *A, int64_t lda, double *Ainv, int64_t ldi, void *work, int64_t work_bytes,
+                 int64_t *info, void *stream);
+int lpx_revised_reinvert_f64(const lpx_revised *s, int update_xB, void *work, int64_t work_bytes, int64_t *info,
+                             void *stream);
+
 /* ------------------------------------------------------------------------------------ batched small LPs */
 /* PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) (primal_solvers.py:176-263) for `batch` independent
  * LPs of one shape, slack or general start basis (Binv0 = B^-1 per LP, or NULL for the identity).  Arrays are

@@ -82,6 +82,9 @@ _SIGS = {
     "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
     "lpx_refine_workspace_bytes": (i64, [i64]),
     "lpx_revised_refine": (C.c_int, [C.POINTER(LpxRevised), i64, C.c_int, vp, i64, vp, vp]),
+    "lpx_invert_workspace_bytes": (i64, [i64]),
+    "lpx_dinverse": (C.c_int, [i64, vp, i64, vp, i64, vp, i64, vp, vp]),
+    "lpx_revised_reinvert_f64": (C.c_int, [C.POINTER(LpxRevised), C.c_int, vp, i64, vp, vp]),
     "lpx_dgemm": (C.c_int, [C.c_int, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64, C.c_double, vp,
                             i64, vp]),
     "lpx_tableau_dual_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),

@@ -1,4 +1,5 @@
-// lpx_refine.hip -- opt-in numerical hygiene for the revised form: refine the product-form inverse in fp64.
+// lpx_refine.hip -- opt-in numerical hygiene for the revised form: refine the product-form inverse in fp64
+// (Newton-Schulz, first half of this file) or rebuild it from the basis columns (blocked Gauss-Jordan, second half).
 //
 // The reference never re-inverts in its revised solvers (primal_solvers.py:247-249 multiplies eta matrices for the
 // whole solve); its only reinversion is the naive solvers' np.linalg.inv per pivot (primal_solvers.py:92-94).  On
@@ -118,8 +119,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // D tile element of lane l, register q of an MFMA tile: row l/16 + 4*q, column l%16 (measured: tools/dbg_gemm.py)
+    // C is read in batches of 4*WT values per lane ahead of their use: one exposed round trip per batch instead of one
+    // per element (at K = 64, the reinversion's trailing update, the epilogue is most of the kernel)
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WT; ++i) {
+        double cv[WT][4];
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t r = row0 + wm + i * 16 + (lane >> 4) + 4 * q, c = col0 + wn + j * 16 + (lane & 15);
+                cv[j][q] = (g.C && r < g.M && c < g.N) ? g.C[r * g.ldc + c] : 0.0;
+            }
 #pragma unroll
         for (int j = 0; j < WT; ++j)
 #pragma unroll
@@ -127,11 +138,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int64_t r = row0 + wm + i * 16 + (lane >> 4) + 4 * q, c = col0 + wn + j * 16 + (lane & 15);
                 if (r < g.M && c < g.N) {
                     double v = g.alpha * acc[i][j][q];
-                    if (g.C) v = fma(g.beta, g.C[r * g.ldc + c], v);
+                    if (g.C) v = fma(g.beta, cv[j][q], v);
                     if (r == c) v += g.gamma;
                     g.D[r * g.ldd + c] = v;
                 }
             }
+    }
 }
 
 static int gemm_check(const GemmArgs &g)
@@ -245,6 +257,309 @@ extern "C" int lpx_revised_refine(const lpx_revised *s, int64_t steps, int updat
     }
     gemm_launch<true>(gr, st);
     hipLaunchKernelGGL(k_absmax, dim3(256), dim3(LPX_BLOCK), 0, st, (const double *)R, m, m, ld, resid + 1);
+    if (update_xB) hipLaunchKernelGGL(k_refine_xb, dim3((unsigned)lpx_cdiv(m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st, *s);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reinversion: B^-1 from scratch in fp64
+// ---------------------------------------------------------------------------------------------------------
+// The reference's only reinversion is np.linalg.inv(A[:, basis]) (primal_solvers.py:92-94, LAPACK getrf + getri).
+// Here: in-place blocked Gauss-Jordan with partial pivoting, 64 columns per block.
+//   1. pivot search: LU with partial pivoting on a scratch copy of the block's columns (rows >= k0), one launch per
+//      column, ping-ponging between two copies so that no kernel reads what it writes; only the pivot rows are kept
+//   2. the 64 row swaps are applied to the whole matrix (and to the row-identity vector `id`)
+//   3. P = W[K, K] is inverted in LDS by one workgroup (no pivoting needed: its pivots are those of step 1)
+//   4. V = W[:, K] with rows K zeroed; W[:, K] = unit columns; R = P^-1 W[K, :]; W[K, :] = R; W -= V R
+//      -- the last is an m x m x 64 GEMM on the matrix cores and carries all 2 m^3 flop of the inversion
+//   5. the row swaps come back as a column permutation: out[:, id[r]] = W[:, r]
+#define INV_NB 64
+#define INV_ROWS 64 /* panel rows per workgroup: 16 per wave, lane = panel column */
+
+struct InvWs {
+    double *W, *V, *R, *S[2], *Pinv, *pv[2], *anorm;
+    int64_t *pi[2], *piv, *id, *inv;
+    int64_t ldw;
+};
+static inline int64_t inv_ldw(int64_t m) { return lpx_roundup(m, 16); }
+extern "C" int64_t lpx_invert_workspace_bytes(int64_t m)
+{
+    if (m <= 0) return 0;
+    const int64_t np = lpx_cdiv(m, INV_ROWS);
+    return 8 * (m * inv_ldw(m) + 3 * m * INV_NB + INV_NB * inv_ldw(m) + INV_NB * INV_NB + 4 * np + 3 * m + 2) + 512;
+}
+static InvWs inv_carve(int64_t m, void *work)
+{
+    InvWs w;
+    const int64_t np = lpx_cdiv(m, INV_ROWS);
+    w.ldw = inv_ldw(m);
+    double *p = (double *)work;
+    w.W = p; p += m * w.ldw;
+    w.R = p; p += INV_NB * w.ldw;
+    w.V = p; p += m * INV_NB;
+    w.S[0] = p; p += m * INV_NB;
+    w.S[1] = p; p += m * INV_NB;
+    w.Pinv = p; p += INV_NB * INV_NB;
+    w.pv[0] = p; p += np;
+    w.pv[1] = p; p += np;
+    w.anorm = p; p += 2;
+    int64_t *q = (int64_t *)p;
+    w.pi[0] = q; q += np;
+    w.pi[1] = q; q += np;
+    w.piv = q; q += m;
+    w.id = q; q += m;
+    w.inv = q;
+    return w;
+}
+
+// partial of one workgroup for the next column's pivot search: (-|x|, row), so that "smallest value, then lowest
+// index" is the largest magnitude with the first row on ties (LAPACK's idamax order)
+__device__ __forceinline__ void inv_publish(double best, int64_t brow, int col_lane, double *pv, int64_t *pi)
+{
+    __shared__ double bv[LPX_WAVES];
+    __shared__ int64_t bi[LPX_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == col_lane) { bv[wave] = best; bi[wave] = brow; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = -1.0;
+        int64_t r = LPX_NOIDX;
+        for (int k = 0; k < LPX_WAVES; ++k) // waves hold ascending rows: strict > keeps the first
+            if (bv[k] > b) { b = bv[k]; r = bi[k]; }
+        pv[blockIdx.x] = r == LPX_NOIDX ? LPX_INF : -b;
+        pi[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_init(int64_t *id, int64_t *info, double *anorm, int64_t m)
+{
+    const int64_t r = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (r < m) id[r] = r;
+    if (r == 0) { info[0] = 0; anorm[0] = 0.0; }
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_panel_load(const double *W, int64_t ldw, int64_t m, int64_t k0, int w,
+                                                              double *S, double *pv, int64_t *pi)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = k0 + (int64_t)blockIdx.x * INV_ROWS + wave * (INV_ROWS / LPX_WAVES);
+    double best = -1.0;
+    int64_t brow = LPX_NOIDX;
+    for (int t = 0; t < INV_ROWS / LPX_WAVES; ++t) {
+        const int64_t r = r0 + t;
+        if (r >= m) break;
+        const double x = lane < w ? W[r * ldw + k0 + lane] : 0.0;
+        S[r * INV_NB + lane] = x;
+        const double a = fabs(x);
+        if (a > best) { best = a; brow = r; }
+    }
+    inv_publish(best, brow, 0, pv, pi);
+}
+
+// column i of the block: pick its pivot row from the partials of the previous launch, eliminate it from the rows
+// below (reading Sin, writing Sout; the row swap happens on the way) and leave the partials for column i+1
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_panel_step(const double *Sin, double *Sout, int64_t m, int64_t k0, int w, int i,
+                                                              const double *pvin, const int64_t *piin, int64_t np, double *pvout,
+                                                              int64_t *piout, int64_t *piv, int64_t *info, const double *anorm)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = k0 + i;
+    // the rows' loads do not depend on the pivot choice: issue them first, the partials' round trip runs beside them
+    constexpr int RPW = INV_ROWS / LPX_WAVES;
+    const int64_t r0 = k0 + (int64_t)blockIdx.x * INV_ROWS + wave * RPW;
+    double src[RPW];
+    if (i + 1 < w) {
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) src[t] = (r0 + t < m && r0 + t > c) ? Sin[(r0 + t) * INV_NB + lane] : 0.0;
+    }
+    const double crow = Sin[c * INV_NB + lane];
+    // every wave combines the partials for itself: no LDS round, no barrier on the way to the pivot row's address
+    VI top{LPX_INF, LPX_NOIDX};
+    for (int64_t k = lane; k < np; k += 64)
+        if (vi_less(pvin[k], piin[k], top.v, top.i)) { top.v = pvin[k]; top.i = piin[k]; }
+    top = wave_argmin(top);
+    int64_t p = top.i;
+    // no candidate above m * eps * max|A| (or only NaNs): singular to working precision.  LAPACK flags exact zeros only;
+    // a simplex basis with a repeated column leaves rounding dust there, hence the threshold.
+    const bool bad = !(-top.v > (double)m * 2.220446049250313e-16 * anorm[0]) || p == LPX_NOIDX;
+    if (bad) p = c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        piv[c] = p;
+        if (bad && info[0] == 0) info[0] = c + 1;
+    }
+    if (i + 1 >= w) return; // last column of the block: only its pivot row was wanted
+    const double prow = Sin[p * INV_NB + lane];
+    const double pivot = __shfl(prow, i);
+    double best = -1.0;
+    int64_t brow = LPX_NOIDX;
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+        const int64_t r = r0 + t;
+        if (r >= m || r <= c) continue;
+        const double x = r == p ? crow : src[t];
+        const double l = __shfl(x, i) / pivot;
+        const double out = fma(-l, prow, x);
+        Sout[r * INV_NB + lane] = out;
+        const double a = fabs(out);
+        if (a > best) { best = a; brow = r; }
+    }
+    inv_publish(best, brow, i + 1, pvout, piout);
+}
+
+// the block's row swaps, in order, on every column of W; thread m carries the row-identity vector
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_swap(double *W, int64_t ldw, int64_t m, int64_t k0, int w, const int64_t *piv,
+                                                        int64_t *id)
+{
+    const int64_t j = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (j > m) return;
+    for (int i = 0; i < w; ++i) {
+        const int64_t c = k0 + i, p = piv[c];
+        if (p == c) continue;
+        if (j < m) {
+            const double a = W[c * ldw + j], b = W[p * ldw + j];
+            W[c * ldw + j] = b;
+            W[p * ldw + j] = a;
+        } else {
+            const int64_t a = id[c], b = id[p];
+            id[c] = b;
+            id[p] = a;
+        }
+    }
+}
+
+// P^-1 of the w x w diagonal block, Gauss-Jordan in LDS by one workgroup
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_block(const double *W, int64_t ldw, int64_t k0, int w, double *Pinv)
+{
+    __shared__ double P[INV_NB][INV_NB + 1];
+    __shared__ double colk[INV_NB], rowk[INV_NB];
+    const int j = threadIdx.x & 63, i0 = threadIdx.x >> 6;
+    for (int q = 0; q < INV_NB / LPX_WAVES; ++q) {
+        const int i = i0 + LPX_WAVES * q;
+        P[i][j] = (i < w && j < w) ? W[(k0 + i) * ldw + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int k = 0; k < w; ++k) {
+        if (threadIdx.x < INV_NB) {
+            colk[threadIdx.x] = P[threadIdx.x][k];
+            rowk[threadIdx.x] = (threadIdx.x == k ? 1.0 : P[k][threadIdx.x]) / P[k][k];
+        }
+        __syncthreads();
+        for (int q = 0; q < INV_NB / LPX_WAVES; ++q) {
+            const int i = i0 + LPX_WAVES * q;
+            P[i][j] = i == k ? rowk[j] : fma(-colk[i], rowk[j], j == k ? 0.0 : P[i][j]);
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < INV_NB / LPX_WAVES; ++q) {
+        const int i = i0 + LPX_WAVES * q;
+        Pinv[i * INV_NB + j] = P[i][j];
+    }
+}
+
+// V = W[:, K] with rows K zeroed; W[:, K] = unit columns
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_setup(double *W, int64_t ldw, int64_t m, int64_t k0, int w, double *V)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * INV_ROWS + wave * (INV_ROWS / LPX_WAVES);
+    for (int t = 0; t < INV_ROWS / LPX_WAVES; ++t) {
+        const int64_t r = r0 + t;
+        if (r >= m) break;
+        double v = 0.0;
+        if (lane < w) {
+            const bool inK = r >= k0 && r < k0 + w;
+            if (!inK) v = W[r * ldw + k0 + lane];
+            W[r * ldw + k0 + lane] = r == k0 + lane ? 1.0 : 0.0;
+        }
+        V[r * INV_NB + lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_invperm(const int64_t *id, int64_t *inv, int64_t m)
+{
+    const int64_t r = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (r < m) inv[id[r]] = r;
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_inv_gather(const double *W, int64_t ldw, const int64_t *inv, double *out, int64_t ldo,
+                                                          int64_t m)
+{
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (j < m) out[i * ldo + j] = W[i * ldw + inv[j]];
+}
+
+// inverts ws.W in place (up to the column permutation kept in ws.id) and writes the inverse to out
+static void inv_run(const InvWs &ws, int64_t m, double *out, int64_t ldo, int64_t *info, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_inv_init, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, ws.id, info, ws.anorm, m);
+    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(LPX_BLOCK), 0, st, (const double *)ws.W, m, m, ws.ldw, ws.anorm);
+    for (int64_t k0 = 0; k0 < m; k0 += INV_NB) {
+        const int w = (int)(m - k0 < INV_NB ? m - k0 : INV_NB);
+        const int64_t np = lpx_cdiv(m - k0, INV_ROWS);
+        hipLaunchKernelGGL(k_inv_panel_load, dim3((unsigned)np), dim3(LPX_BLOCK), 0, st, (const double *)ws.W, ws.ldw, m, k0, w, ws.S[0],
+                           ws.pv[0], ws.pi[0]);
+        for (int i = 0; i < w; ++i)
+            hipLaunchKernelGGL(k_inv_panel_step, dim3((unsigned)np), dim3(LPX_BLOCK), 0, st, (const double *)ws.S[i & 1], ws.S[(i + 1) & 1],
+                               m, k0, w, i, (const double *)ws.pv[i & 1], (const int64_t *)ws.pi[i & 1], np, ws.pv[(i + 1) & 1],
+                               ws.pi[(i + 1) & 1], ws.piv, info, (const double *)ws.anorm);
+        hipLaunchKernelGGL(k_inv_swap, dim3((unsigned)lpx_cdiv(m + 1, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, ws.W, ws.ldw, m, k0, w,
+                           (const int64_t *)ws.piv, ws.id);
+        hipLaunchKernelGGL(k_inv_block, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)ws.W, ws.ldw, k0, w, ws.Pinv);
+        hipLaunchKernelGGL(k_inv_setup, dim3((unsigned)lpx_cdiv(m, INV_ROWS)), dim3(LPX_BLOCK), 0, st, ws.W, ws.ldw, m, k0, w, ws.V);
+        double *rows = ws.W + k0 * ws.ldw;
+        const GemmArgs gr{ws.Pinv, rows, nullptr, ws.R, w, m, w, INV_NB, ws.ldw, 0, ws.ldw, 1.0, 0.0, 0.0}; // R = P^-1 W[K, :]
+        gemm_launch<false>(gr, st);
+        hipLaunchKernelGGL(k_copy2d, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK), (unsigned)w), dim3(LPX_BLOCK), 0, st, (const double *)ws.R,
+                           ws.ldw, rows, ws.ldw, (int64_t)w, m);
+        const GemmArgs gu{ws.V, ws.R, ws.W, ws.W, m, m, w, INV_NB, ws.ldw, ws.ldw, ws.ldw, -1.0, 1.0, 0.0}; // W -= V R
+        gemm_launch<false>(gu, st);
+    }
+    hipLaunchKernelGGL(k_inv_invperm, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, (const int64_t *)ws.id, ws.inv, m);
+    hipLaunchKernelGGL(k_inv_gather, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK), (unsigned)m), dim3(LPX_BLOCK), 0, st, (const double *)ws.W,
+                       ws.ldw, (const int64_t *)ws.inv, out, ldo, m);
+}
+
+// Ainv = A^-1 (fp64, row-major, m x m; Ainv may be A).  info (device, one int64): 0, or 1 + the first column whose
+// pivot candidates were all below m * eps * max|A| or NaN (then Ainv is not an inverse) -- numpy's
+// LinAlgError("Singular matrix").
+extern "C" int lpx_dinverse(int64_t m, const double *A, int64_t lda, double *Ainv, int64_t ldi, void *work, int64_t work_bytes,
+                            int64_t *info, void *stream)
+{
+    LPX_REQUIRE(m > 0 && A && Ainv && info, "null / empty matrix");
+    LPX_REQUIRE(lda >= m && ldi >= m, "leading dimension too small");
+    LPX_REQUIRE(m <= 65535, "m beyond the grid's y range");
+    LPX_REQUIRE(work && work_bytes >= lpx_invert_workspace_bytes(m) && lpx_aligned16(work), "workspace too small");
+    const InvWs ws = inv_carve(m, work);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK), (unsigned)m), dim3(LPX_BLOCK), 0, st, A, lda, ws.W, ws.ldw, m, m);
+    inv_run(ws, m, Ainv, ldi, info, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// W[i][k] = A[i][basis[k]] as fp64
+__global__ __launch_bounds__(LPX_BLOCK) void k_gather_basis(lpx_revised s, double *W, int64_t ld)
+{
+    const int64_t i = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (k < s.m) W[i * ld + k] = (double)s.A[i * s.ldA + s.basis[k]];
+}
+__global__ void k_inv_end(lpx_ctrl *ctrl) { ctrl->f32_phase = 0; } // a fresh fp64 inverse ends the float32 phase
+
+// s->Binv = inv(A[:, basis]) from scratch in fp64; update_xB != 0: x_B = B^-1 b afterwards.  info as in lpx_dinverse.
+// Opt-in (RevisedEngine.reinvert): the reference's revised solvers never re-invert.
+extern "C" int lpx_revised_reinvert_f64(const lpx_revised *s, int update_xB, void *work, int64_t work_bytes, int64_t *info, void *stream)
+{
+    LPX_REQUIRE(s && s->m > 0 && s->A && s->Binv && s->basis && s->ctrl && s->b && s->xB, "null state");
+    LPX_REQUIRE(s->m <= 65535, "m beyond the grid's y range");
+    LPX_REQUIRE(work && work_bytes >= lpx_invert_workspace_bytes(s->m) && lpx_aligned16(work), "workspace too small");
+    LPX_REQUIRE(info != nullptr, "null info");
+    const int64_t m = s->m;
+    const InvWs ws = inv_carve(m, work);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gather_basis, dim3((unsigned)lpx_cdiv(m, LPX_BLOCK), (unsigned)m), dim3(LPX_BLOCK), 0, st, *s, ws.W, ws.ldw);
+    inv_run(ws, m, s->Binv, s->ldB, info, st);
+    hipLaunchKernelGGL(k_inv_end, dim3(1), dim3(1), 0, st, s->ctrl);
     if (update_xB) hipLaunchKernelGGL(k_refine_xb, dim3((unsigned)lpx_cdiv(m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st, *s);
     LPX_LAUNCH_CHECK();
     return LPX_OK;

@@ -78,11 +78,14 @@ class RevisedEngine:
     # ------------------------------------------------------------------ loop
     #: opt-in: refine B^-1 (lpx_revised_refine) every this many pivots inside run(); None = never (the reference's loop)
     refine_every = None
+    #: opt-in: re-invert from scratch (lpx_revised_reinvert_f64) every this many pivots inside run(); None = never
+    reinvert_every = None
 
     def run(self, kind, maxiters):
         """One ``solve(maxiters)`` call of the reference: returns the control block after the loop ended."""
         st = stream_ptr()
         last_refine = None
+        last_reinvert = None
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         left = int(maxiters)
         ctrl = None
@@ -103,6 +106,12 @@ class RevisedEngine:
                 if int(ctrl.pivots) - last_refine >= int(self.refine_every):
                     self.refine(steps=1, update_xB=kind != _lib.KIND_BOUNDED)
                     last_refine = int(ctrl.pivots)
+            if self.reinvert_every and not self.naive:
+                if last_reinvert is None:
+                    last_reinvert = int(ctrl.pivots) - int(ctrl.counter)
+                if int(ctrl.pivots) - last_reinvert >= int(self.reinvert_every):
+                    self.reinvert(update_xB=kind != _lib.KIND_BOUNDED)
+                    last_reinvert = int(ctrl.pivots)
         if ctrl is None:
             ctrl = self.read_ctrl()
         return ctrl
@@ -132,6 +141,19 @@ class RevisedEngine:
                                                resid.data_ptr(), stream_ptr()))
         r = resid.cpu().numpy()
         return float(r[0]), float(r[1])
+
+    def reinvert(self, update_xB=True):
+        """Opt-in: B^-1 = inv(A[:, basis]) from scratch in fp64 (lpx_revised_reinvert_f64: blocked Gauss-Jordan, trailing
+        updates on the matrix cores) and, with update_xB, x_B = B^-1 b.  Raises numpy's LinAlgError for a singular basis,
+        as np.linalg.inv does (primal_solvers.py:92-94).  Not part of the reference's revised loop."""
+        torch = self.torch
+        nbytes = self.lib.lpx_invert_workspace_bytes(self.m)
+        work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        info = torch.zeros(1, dtype=torch.int64, device="cuda")
+        _lib.check(self.lib.lpx_revised_reinvert_f64(C.byref(self.s), int(bool(update_xB)), work.data_ptr(), nbytes,
+                                                     info.data_ptr(), stream_ptr()))
+        if int(info.item()) != 0:
+            raise np.linalg.LinAlgError("Singular matrix")
 
     # ------------------------------------------------------------------ results
     def expand(self):

@@ -105,6 +105,13 @@ class PrimalNaiveSimplexSolver:
             raise ValueError("the naive solvers re-invert every pivot; there is nothing to refine")
         return self._engine.refine(steps=steps, update_xB=True)
 
+    def reinvert(self):
+        """Opt-in extension: ``inv_basis_matrix = inv(A[:, basis])`` from scratch in float64 on the device (what the naive
+        solvers do per pivot in float32, primal_solvers.py:92-94) and ``bfs`` from it.  ``solve()`` never calls it."""
+        if self._NAIVE:
+            raise ValueError("the naive solvers re-invert every pivot")
+        self._engine.reinvert(update_xB=True)
+
     def _raise_for_status(self, status):
         if status == _lib.PRIMAL_UNBOUNDED:
             raise PrimalIsUnboundedError  # primal_solvers.py:130-132

@@ -300,6 +300,66 @@ def test_primal_dual_warm_start_same_optimum_fewer_pivots(m, n, seed):
     print(f"inner pivots cold {cold.inner_pivots} warm {warm.inner_pivots}, outer {rc.iters} / {rw.iters}")
 
 
+@pytest.mark.parametrize("m,n,seed", [(5, 12, 1), (64, 128, 3), (300, 650, 4), (1000, 2000, 5)])
+def test_reinvert_rebuilds_the_inverse_from_the_basis(m, n, seed):
+    """Opt-in reinversion (lpx_revised_reinvert_f64, SURVEY.md 8f-3): after some pivots B^-1 is overwritten with garbage;
+    reinvert() rebuilds it from A[:, basis] alone (np.linalg.inv's job at primal_solvers.py:92-94), x_B follows, and the
+    solve continues to the oracle's optimum."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(m, n, seed)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    s.solve(min(200, 3 * m))
+    eng = s._engine
+    eng.Binv.fill_(float("nan"))
+    eng.xB.fill_(-1.0)
+    s.reinvert()
+    A32 = np.asarray(A, dtype=np.float32).astype(np.float64)
+    Bm = A32[:, eng.host_basis()]
+    assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(m))) < 1e-10
+    assert np.max(np.abs(eng.host_Binv() - np.linalg.inv(Bm))) <= 1e-9 * np.max(np.abs(np.linalg.inv(Bm)))
+    xB = np.linalg.solve(Bm, np.asarray(b, dtype=np.float32).astype(np.float64))
+    assert np.max(np.abs(eng.host_xB() - xB)) <= 1e-9 * max(1.0, np.max(np.abs(xB)))
+    if m <= 300:
+        res = s.solve(100000)
+        want = O.OracleRevised(c, A, b, basis, log_cap=4).solve(100000)
+        assert res.optimum and want.status == O.OPTIMAL
+        assert abs(res.cost - want.cost) <= 1e-9 * max(1.0, abs(want.cost))
+    else:
+        res = s.solve(300)
+        Bm = A32[:, eng.host_basis()]
+        assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(m))) < 1e-9
+        assert np.max(np.abs(A32 @ res.x - np.asarray(b, dtype=np.float32))) < 1e-8
+
+
+def test_reinvert_of_a_singular_basis_raises_like_numpy():
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+
+    c, A, b, basis = gen.gen_primal(20, 40, 2)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    s._engine.basis[1] = s._engine.basis[0]  # the same column twice
+    with pytest.raises(np.linalg.LinAlgError):
+        s.reinvert()
+
+
+def test_reinvert_every_keeps_a_long_run_exact():
+    """Opt-in periodic reinversion inside solve() (engine.reinvert_every), same long Bland run as below."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+
+    cs = [c for c in load("random_large.json") if c["m"] == 256][0]
+    c, A, b, basis = problem_of(cs)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    s._engine.reinvert_every = 500
+    res = s.solve(100000)
+    assert res.optimum
+    assert abs(res.cost - cs["ref"]["cost"]) <= 1e-9 * max(1.0, abs(cs["ref"]["cost"]))
+    assert sorted(res.basis.tolist()) == sorted(cs["ref"]["basis"])
+    eng = s._engine
+    Bm = np.asarray(A, dtype=np.float32).astype(np.float64)[:, eng.host_basis()]
+    assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(256))) < 1e-10
+
+
 def test_refine_every_keeps_a_long_run_exact():
     """Opt-in periodic refinement inside solve() (engine.refine_every): the full Bland solve of gen_primal(256, 512, 0)
     (3470 pivots in the reference) still ends on the reference's optimum, and the final inverse is exact to 1e-12."""
