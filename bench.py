@@ -283,7 +283,7 @@ def bench_revised(args):
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"gen_primal_columns(m={m}, n={n}, seed={args.seed}) PrimalRevisedSimplexSolver loop",
                       "m": m, "n": n, "form": "revised"},
-           "roofline": {"bound": "hbm", "kernel": "k_rank1<revised>", "achieved": 16.0 * m * m / k1_s / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "k_rank1_y<revised> (B^-1 update + the next iteration's y partials)", "achieved": 16.0 * m * m / k1_s / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 16.0 * m * m / k1_s / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "avg_launch_ms": k1_s * 1e3,
                         "whole_iteration_GBs": iter_bytes * K / dt / 1e9},

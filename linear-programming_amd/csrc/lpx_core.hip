@@ -941,6 +941,25 @@ static void launch_update(const lpx_revised *s, const RevisedWs &w, bool update_
     lpx_rank1_launch<false>(p, a, st);
     lpx_k1_end(st);
 }
+// K1 that also leaves the next iteration's y partials (k_rank1_y): grid and chunking are the y pass's
+static inline bool revised_fuse_y(const RevisedWs &w)
+{
+    return lpx_env_int("LPX_FUSE_Y", 1) != 0 && colsum_lds_bytes(w.py.rpc) != 0 && colsum_lds_bytes(w.pa.rpc) != 0;
+}
+static void launch_update_y(const lpx_revised *s, const RevisedWs &w, bool update_xB, hipStream_t st)
+{
+    Rank1Args a{};
+    a.M = s->Binv; a.rows = s->m; a.cols = s->m; a.ld = s->ldB; a.e = w.e; a.rowr = w.rowr; a.r = -1;
+    a.ctrl = s->ctrl; a.xB = update_xB ? s->xB : nullptr; a.xr_old = w.scal; a.col0 = 0;
+    a.rows_per_block = w.py.rpc;
+    const Rank1YArgs f{s->c, s->basis, w.ypart, w.ldyp};
+    const dim3 grid((unsigned)w.py.nstrips, (unsigned)w.py.nch);
+    const size_t lds = colsum_lds_bytes(w.py.rpc);
+    lpx_k1_begin(st);
+    if (lpx_stream_nt(8 * s->m * s->ldB)) hipLaunchKernelGGL((k_rank1_y<1, 4>), grid, dim3(w.py.threads), lds, st, a, f);
+    else hipLaunchKernelGGL((k_rank1_y<0, 4>), grid, dim3(w.py.threads), lds, st, a, f);
+    lpx_k1_end(st);
+}
 static void launch_bounded_bfs(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
 {
     hipLaunchKernelGGL(k_bounded_w, dim3((unsigned)lpx_cdiv(s->m, LPX_WAVES)), dim3(LPX_BLOCK), 0, st, *s, w.w);
@@ -984,41 +1003,54 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
     hipStream_t st0 = (hipStream_t)stream;
     const lpx_revised sv = *s;
     const lpx_revised *sp = &sv;
+    // fuse: the y partials of an iteration come from the previous iteration's K1 (k_rank1_y); only the first iteration
+    // of a call computes them itself (the caller may have changed B^-1 or the basis in between).  A bound flip or a
+    // terminal status skips K1 and leaves B^-1, the basis and therefore the partials as they are.
+    const bool fuse = revised_fuse_y(w);
+    auto sums = [&](hipStream_t st) {
+        if (fuse) launch_colsum_A(sp, w, W_YPART, w.zpart, st);
+        else launch_pricing_sums(sp, w, st);
+    };
+    auto update = [&](bool update_xB, hipStream_t st) {
+        if (fuse) launch_update_y(sp, w, update_xB, st);
+        else launch_update(sp, w, update_xB, st);
+    };
     auto one = [&](hipStream_t st) {
         if (kind == LPX_KIND_PRIMAL) {
-            launch_pricing_sums(sp, w, st);
+            sums(st);
             launch_fin(sp, w, FIN_PRIMAL, nullptr, st);
             launch_direction(sp, w, DIR_PRIMAL, -1, st);
             launch_prepare(sp, w, PREP_PRIMAL, -1, st);
-            launch_update(sp, w, true, st);
+            update(true, st);
         } else if (kind == LPX_KIND_DUAL) {
             hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)sp->xB, sp->m, sp->ctrl);
             launch_colsum_A(sp, w, W_BINV_ROW, w.zpart2, st);
-            launch_pricing_sums(sp, w, st);
+            sums(st);
             launch_fin(sp, w, FIN_DUAL, nullptr, st);
             launch_direction(sp, w, DIR_DUAL, -1, st);
             launch_prepare(sp, w, PREP_DUAL, -1, st);
-            launch_update(sp, w, true, st);
+            update(true, st);
         } else {
             hipLaunchKernelGGL(k_clear_flip, dim3(1), dim3(1), 0, st, sp->ctrl);
-            launch_pricing_sums(sp, w, st);
+            sums(st);
             launch_fin(sp, w, FIN_BOUNDED, nullptr, st);
             launch_direction(sp, w, DIR_BOUNDED, -1, st);
             launch_prepare(sp, w, PREP_BOUNDED, -1, st);
-            launch_update(sp, w, false, st);
+            update(false, st);
             launch_bounded_bfs(sp, w, st);
         }
     };
     struct {
         lpx_revised s;
-        int kind, vpt, unroll, nt, threads;
+        int kind, vpt, unroll, nt, threads, fuse;
         int64_t rpb;
     } key;
     memset(&key, 0, sizeof key);
     const Rank1Plan plan = lpx_rank1_plan(s->m, s->m);
     key.s = sv; key.kind = kind; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt;
-    key.threads = plan.threads; key.rpb = plan.rows_per_block;
+    key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse;
     if (iters <= 0) return LPX_OK;
+    if (fuse) launch_colsum_B(sp, w, st0);
     return lpx_run_iterations(&key, sizeof key, iters, st0, one);
 }
 

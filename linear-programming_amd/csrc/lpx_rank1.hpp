@@ -187,6 +187,91 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
     }
 }
 
+// Revised form: K1 fused with the NEXT iteration's y pass.  y = c_B B^-1 (primal_solvers.py:64) is a weighted column
+// sum of the matrix K1 has just produced, so the workgroup that writes a row chunk of the new B^-1 also leaves that
+// chunk's partial column sums -- 8 m^2 bytes of the next iteration (its k_colsum<double> launch) never leave HBM.
+// The price is K1's flat mapping: the grid is the column-sum grid (strips x row chunks, ~2 workgroups per CU, each
+// walking down its chunk), 5.4 instead of 6.1 TB/s for the update itself at m = 10000, 34 us lost against 122 us saved.
+// The partials are bit-identical to k_colsum's: same chunks, same sequential fma chain per column, same weights.
+struct Rank1YArgs {
+    const float *c;       // weights c[basis[i]] (basis already holds the entering variable: k_prepare ran)
+    const int64_t *basis;
+    double *ypart;        // [chunk][ldyp]
+    int64_t ldyp;
+};
+template <int NT, int UNROLL>
+__global__ __launch_bounds__(LPX_BLOCK) void k_rank1_y(Rank1Args a, Rank1YArgs f)
+{
+    extern __shared__ __attribute__((aligned(16))) char rank1y_lds[];
+    double *wl = (double *)rank1y_lds;
+    if (a.ctrl->status != LPX_RUNNING || a.ctrl->flip) return;
+    const int64_t r = a.ctrl->leave_r;
+    const int nthr = blockDim.x;
+    const int64_t row0 = (int64_t)blockIdx.y * a.rows_per_block;
+    const int64_t row1 = (row0 + a.rows_per_block < a.rows) ? row0 + a.rows_per_block : a.rows;
+    const double *__restrict__ e = a.e;
+    for (int64_t i = row0 + threadIdx.x; i < row1; i += nthr) wl[i - row0] = (double)f.c[f.basis[i]];
+    if (a.xB != nullptr && blockIdx.x == 0) { // primal_solvers.py:251-253  bfs = E @ bfs
+        const double xr = *a.xr_old;
+        for (int64_t i = row0 + threadIdx.x; i < row1; i += nthr) {
+            const double ei = e[i];
+            a.xB[i] = (i == r) ? ei * xr : fma(ei, xr, a.xB[i]);
+        }
+    }
+    __syncthreads();
+    const int64_t col = ((int64_t)blockIdx.x * nthr + threadIdx.x) * 2;
+    if (col >= a.cols) return;
+    const d2_t pr = *(const d2_t *)(a.rowr + col);
+    const int64_t ld = a.ld;
+    d2_t acc{0.0, 0.0};
+    double *p = a.M + row0 * ld + col;
+    int64_t i = row0;
+    for (; i + UNROLL <= row1; i += UNROLL) {
+        d2_t x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = lpx_ld2<NT>(p + u * ld);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const double ei = e[i + u];
+            if ((i + u) == r) {
+                x[u][0] = ei * pr[0];
+                x[u][1] = ei * pr[1];
+            } else {
+                x[u][0] = fma(ei, pr[0], x[u][0]);
+                x[u][1] = fma(ei, pr[1], x[u][1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) lpx_st2<NT>(p + u * ld, x[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const double w = wl[i + u - row0];
+            acc[0] = fma(w, x[u][0], acc[0]);
+            acc[1] = fma(w, x[u][1], acc[1]);
+        }
+        p += UNROLL * ld;
+    }
+    for (; i < row1; ++i) {
+        const double ei = e[i];
+        d2_t x0 = lpx_ld2<NT>(p);
+        if (i == r) {
+            x0[0] = ei * pr[0];
+            x0[1] = ei * pr[1];
+        } else {
+            x0[0] = fma(ei, pr[0], x0[0]);
+            x0[1] = fma(ei, pr[1], x0[1]);
+        }
+        lpx_st2<NT>(p, x0);
+        const double w = wl[i - row0];
+        acc[0] = fma(w, x0[0], acc[0]);
+        acc[1] = fma(w, x0[1], acc[1]);
+        p += ld;
+    }
+    double *out = f.ypart + (int64_t)blockIdx.y * f.ldyp + col;
+    out[0] = acc[0];
+    if (col + 1 < a.cols) out[1] = acc[1];
+}
+
 // Host-side launch plan.  rows_per_block is chosen so that the grid is many times the ~2048 resident
 // workgroups (256 CUs x 8): a grid that only just exceeds residency has a 2x tail.
 struct Rank1Plan {
@@ -217,7 +302,8 @@ static inline Rank1Plan lpx_rank1_plan(int64_t rows, int64_t cols)
     if (p.nt < 0 || p.nt > 3) p.nt = 0;
     const int64_t nstrips = lpx_cdiv(cols, 2 * (int64_t)p.threads * p.vpt);
     // small problems: shrink the tile until there are enough workgroups to occupy the chip
-    while (rpb > 4 && nstrips * lpx_cdiv(rows, rpb) < 1024) rpb /= 2;
+    const int64_t minwg = lpx_env_int("LPX_RANK1_MINWG", 1024);
+    while (rpb > 4 && nstrips * lpx_cdiv(rows, rpb) < minwg) rpb /= 2;
     if (rpb < p.unroll) p.unroll = rpb >= 8 ? 8 : rpb >= 4 ? 4 : rpb >= 2 ? 2 : 1;
     p.rows_per_block = rpb;
     p.grid = dim3((unsigned)nstrips, (unsigned)lpx_cdiv(rows, rpb), 1);
