@@ -84,14 +84,14 @@ struct ColsumPlan {
 // small matrices the workgroup is narrowed (64/128 lanes) until there are enough workgroups to occupy the chip.
 // About two workgroups per CU (strips x chunks ~ 480) streams best: measured on the 10000 x 10000 B^-1, 20 strips,
 // chunks 8 / 16 / 20 / 24 / 32 / 64 -> 1234 / 1527 / 1558 / 1545 / 1504 / 1478 pivots/s for the whole iteration.
-static inline ColsumPlan colsum_plan(int64_t rows, int64_t cols, int V)
+static inline ColsumPlan colsum_plan(int64_t rows, int64_t cols, int V, int64_t maxch_dflt = 32)
 {
     ColsumPlan p;
     p.threads = LPX_BLOCK;
     while (p.threads > 64 && lpx_cdiv(cols, (int64_t)p.threads * V) * 32 < 512) p.threads /= 2;
     p.nstrips = lpx_cdiv(cols, (int64_t)p.threads * V);
     int64_t nch = lpx_cdiv(480, p.nstrips);
-    const int64_t maxch = lpx_env_int("LPX_COLSUM_MAXCH", 32);
+    const int64_t maxch = lpx_env_int("LPX_COLSUM_MAXCH", (int)maxch_dflt);
     if (nch > maxch) nch = maxch;
     if (nch < 1) nch = 1;
     p.rpc = lpx_cdiv(rows, nch);
@@ -104,6 +104,10 @@ struct RevisedWs {
     ColsumPlan py, pa;
     int64_t ldyp, ldzp;
     double *ypart, *y, *zpart, *zpart2, *rc, *row, *d, *e, *rowr, *w, *scal;
+    // staged pricing of the primal loop (see revised_staged_pricing): columns [0, n1) first, the rest only if needed
+    int64_t n1;
+    ColsumPlan p1, p2;
+    double *zpart1;
     lpx_ctrl *scr_ctrl; // scratch control block for the primal-dual steps
     Partials price, ratio;
     int64_t bytes;
@@ -140,6 +144,16 @@ static RevisedWs revised_ws(int64_t m, int64_t n, void *base)
     w.rowr = (double *)carve(p, 8 * (lpx_roundup(m, 2) + 2));
     w.w = (double *)carve(p, 8 * (m + 2));
     w.scal = (double *)carve(p, 8 * 16);
+    w.n1 = 0;
+    w.zpart1 = nullptr;
+    // worth it once a pass over A costs more than the two extra launches (LPX_STAGED_MIN_MB: tests force small cases)
+    if (4 * m * n >= ((int64_t)lpx_env_int("LPX_STAGED_MIN_MB", 64) << 20) && w.pa.nstrips >= 2) {
+        const int64_t strip = (int64_t)w.pa.threads * 4;
+        w.n1 = lpx_cdiv(w.pa.nstrips, 8) * strip;
+        w.p1 = colsum_plan(m, w.n1, 4, 128);
+        w.p2 = colsum_plan(m, n - w.n1, 4);
+        w.zpart1 = (double *)carve(p, 8 * w.p1.nch * w.ldzp);
+    }
     w.scr_ctrl = (lpx_ctrl *)carve(p, sizeof(lpx_ctrl));
     carve_partials(p, w.price);
     carve_partials(p, w.ratio);
@@ -217,7 +231,22 @@ struct ColsumArgs {
     int64_t ynch, yld;
     int lds_weights; // weights staged in dynamic LDS (rpc * 8 bytes)
     int nt;          // matrix larger than the Infinity Cache: non-temporal loads (it is read once per launch)
+    // staged pricing: pricing partials of the columns scanned so far; the launch is skipped when they already decide
+    // the iteration (pricing_resolved)
+    const double *gate_v0;
+    const int64_t *gate_i0;
+    int64_t gate_n;
 };
+
+// primal_solvers.py:135-142 needs two facts about rc: the first index with rc_j < 0 and whether min(rc) passes the
+// optimality test.  A prefix of the columns that holds a negative entry below -1e-8 settles both -- the entering column
+// is its first negative, "not optimal" is certain -- whatever the rest of the row looks like.
+__device__ __forceinline__ bool pricing_resolved(const double *v0, const int64_t *i0, int64_t np, BlockRed &red)
+{
+    const double mn = combine_min(v0, np, red);
+    const int64_t j = combine_imin(i0, np, red);
+    return j != LPX_NOIDX && !lpx_is_optimal_min(mn);
+}
 
 template <typename AccT>
 __device__ __forceinline__ AccT colsum_weight(const ColsumArgs &a, int64_t i, int64_t r)
@@ -322,6 +351,10 @@ template <typename MatT, int V>
 __global__ __launch_bounds__(LPX_BLOCK) void k_colsum(ColsumArgs a)
 {
     if (a.ctrl->status != LPX_RUNNING) return;
+    if (a.gate_n > 0) {
+        __shared__ BlockRed red;
+        if (pricing_resolved(a.gate_v0, a.gate_i0, a.gate_n, red)) return;
+    }
     if (a.ctrl->f32_phase) colsum_body<MatT, float, V, false>(a); // first iteration only
     else if (a.nt) colsum_body<MatT, double, V, true>(a);
     else colsum_body<MatT, double, V, false>(a);
@@ -347,20 +380,31 @@ struct FinArgs {
     double *out2; // dual row
     Partials P;
     const lpx_ctrl *ctrl;
+    // staged pricing (FIN_PRIMAL): this launch covers columns [col0, col0 + cols) -- part points at column col0 --
+    // and writes the pricing partials from index pbase on; gate_n > 0: neutral partials if the earlier stage decided
+    int64_t col0, pbase, gate_n;
 };
 
 __global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
 {
     __shared__ BlockRed red;
     if (a.ctrl->status != LPX_RUNNING) return;
+    if (a.gate_n > 0 && pricing_resolved(a.P.v0, a.P.i0, a.gate_n, red)) {
+        if (threadIdx.x == 0) {
+            a.P.v0[a.pbase + blockIdx.x] = LPX_INF;
+            a.P.i0[a.pbase + blockIdx.x] = LPX_NOIDX;
+        }
+        return;
+    }
     const bool f32 = a.ctrl->f32_phase != 0;
-    const int64_t col = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    const bool in = col < a.cols;
+    const int64_t lcol = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const int64_t col = a.col0 + lcol;
+    const bool in = lcol < a.cols;
     double s = 0.0, s2 = 0.0;
     if (in) {
-        s = f32 ? (double)fin_sum<float>(a.part, a.nch, a.ldp, col) : fin_sum<double>(a.part, a.nch, a.ldp, col);
+        s = f32 ? (double)fin_sum<float>(a.part, a.nch, a.ldp, lcol) : fin_sum<double>(a.part, a.nch, a.ldp, lcol);
         if (a.mode == FIN_DUAL)
-            s2 = f32 ? (double)fin_sum<float>(a.part2, a.nch, a.ldp, col) : fin_sum<double>(a.part2, a.nch, a.ldp, col);
+            s2 = f32 ? (double)fin_sum<float>(a.part2, a.nch, a.ldp, lcol) : fin_sum<double>(a.part2, a.nch, a.ldp, lcol);
     }
     if (a.mode == FIN_Y) {
         if (in) a.out[col] = s;
@@ -376,8 +420,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_finalize(FinArgs a)
             const double mn = block_min(live ? rc : LPX_INF, red);
             const int64_t jn = block_imin((live && rc < 0.0) ? col : LPX_NOIDX, red);
             if (threadIdx.x == 0) {
-                a.P.v0[blockIdx.x] = mn;
-                a.P.i0[blockIdx.x] = jn;
+                a.P.v0[a.pbase + blockIdx.x] = mn;
+                a.P.i0[a.pbase + blockIdx.x] = jn;
             }
         } else {
             double row = 0.0;
@@ -879,17 +923,24 @@ static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_
     a.nt = lpx_stream_nt(8 * s->m * s->ldB);
     hipLaunchKernelGGL((k_colsum<double, 2>), dim3((unsigned)w.py.nstrips, (unsigned)w.py.nch), dim3(w.py.threads), lds, st, a);
 }
-static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
+// columns [col0, col0 + cols) of A with plan p; gate_n > 0: skipped when the first gate_n pricing partials decide
+static void launch_colsum_A_range(const lpx_revised *s, const RevisedWs &w, const ColsumPlan &p, int wmode, double *part,
+                                  int64_t col0, int64_t cols, int64_t gate_n, hipStream_t st)
 {
     ColsumArgs a{};
-    a.M = s->A; a.ld = s->ldA; a.rows = s->m; a.cols = s->n; a.rpc = w.pa.rpc;
+    a.M = s->A + col0; a.ld = s->ldA; a.rows = s->m; a.cols = cols; a.rpc = p.rpc;
     a.wmode = wmode; a.wvec = w.y; a.Binv = s->Binv; a.ldB = s->ldB;
     a.part = part; a.ldp = w.ldzp; a.ctrl = s->ctrl;
     a.ypart = w.ypart; a.ynch = w.py.nch; a.yld = w.ldyp;
-    const size_t lds = colsum_lds_bytes(w.pa.rpc);
+    a.gate_v0 = w.price.v0; a.gate_i0 = w.price.i0; a.gate_n = gate_n;
+    const size_t lds = colsum_lds_bytes(p.rpc);
     a.lds_weights = lds != 0;
     a.nt = lpx_stream_nt(4 * s->m * s->ldA);
-    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)w.pa.nstrips, (unsigned)w.pa.nch), dim3(w.pa.threads), lds, st, a);
+    hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)p.nstrips, (unsigned)p.nch), dim3(p.threads), lds, st, a);
+}
+static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
+{
+    launch_colsum_A_range(s, w, w.pa, wmode, part, 0, s->n, 0, st);
 }
 static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, double *rc_out, hipStream_t st)
 {
@@ -902,6 +953,31 @@ static void launch_fin(const lpx_revised *s, const RevisedWs &w, int mode, doubl
         a.out = rc_out ? rc_out : w.rc; a.out2 = w.row;
     }
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(a.cols, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+}
+// Staged pricing of the primal loop (large A only): z and rc for the first eighth of the columns, then -- gated on the
+// device by pricing_resolved -- for the rest.  Decisions are the reference's exactly; rc of skipped columns is not
+// produced (nothing in the loop reads it).  4 launches, the last two usually empty.
+static inline bool revised_staged_pricing(const RevisedWs &w)
+{
+    return w.n1 > 0 && lpx_env_int("LPX_STAGED_PRICING", 1) != 0 && colsum_lds_bytes(w.p1.rpc) != 0 &&
+           colsum_lds_bytes(w.p2.rpc) != 0;
+}
+static void launch_fin_primal_range(const lpx_revised *s, const RevisedWs &w, const ColsumPlan &p, const double *part,
+                                    int64_t col0, int64_t cols, int64_t gate_n, hipStream_t st)
+{
+    FinArgs a{};
+    a.mode = FIN_PRIMAL; a.ctrl = s->ctrl; a.c = s->c; a.var_state = s->var_state; a.P = w.price;
+    a.cols = cols; a.nch = p.nch; a.ldp = w.ldzp; a.part = part; a.out = w.rc;
+    a.col0 = col0; a.pbase = col0 / LPX_BLOCK; a.gate_n = gate_n;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)lpx_cdiv(cols, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, a);
+}
+static void launch_staged_pricing(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
+{
+    const int64_t nb1 = w.n1 / LPX_BLOCK; // n1 is a whole number of 1024-column strips
+    launch_colsum_A_range(s, w, w.p1, W_YPART, w.zpart1, 0, w.n1, 0, st);
+    launch_fin_primal_range(s, w, w.p1, w.zpart1, 0, w.n1, 0, st);
+    launch_colsum_A_range(s, w, w.p2, W_YPART, w.zpart + w.n1, w.n1, s->n - w.n1, nb1, st);
+    launch_fin_primal_range(s, w, w.p2, w.zpart + w.n1, w.n1, s->n - w.n1, nb1, st);
 }
 // y = c_B B^-1 (row-chunk partials), z = y A with y finished inside the second launch (2 launches)
 static void launch_pricing_sums(const lpx_revised *s, const RevisedWs &w, hipStream_t st)
@@ -1015,10 +1091,15 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
         if (fuse) launch_update_y(sp, w, update_xB, st);
         else launch_update(sp, w, update_xB, st);
     };
+    const bool staged = fuse && kind == LPX_KIND_PRIMAL && revised_staged_pricing(w);
     auto one = [&](hipStream_t st) {
         if (kind == LPX_KIND_PRIMAL) {
-            sums(st);
-            launch_fin(sp, w, FIN_PRIMAL, nullptr, st);
+            if (staged) {
+                launch_staged_pricing(sp, w, st);
+            } else {
+                sums(st);
+                launch_fin(sp, w, FIN_PRIMAL, nullptr, st);
+            }
             launch_direction(sp, w, DIR_PRIMAL, -1, st);
             launch_prepare(sp, w, PREP_PRIMAL, -1, st);
             update(true, st);
@@ -1048,7 +1129,7 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
     memset(&key, 0, sizeof key);
     const Rank1Plan plan = lpx_rank1_plan(s->m, s->m);
     key.s = sv; key.kind = kind; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt;
-    key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse;
+    key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse + 2 * staged;
     if (iters <= 0) return LPX_OK;
     if (fuse) launch_colsum_B(sp, w, st0);
     return lpx_run_iterations(&key, sizeof key, iters, st0, one);

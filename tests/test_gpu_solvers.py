@@ -360,6 +360,33 @@ def test_reinvert_every_keeps_a_long_run_exact():
     assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(256))) < 1e-10
 
 
+@pytest.mark.parametrize("m,n,seed", [(40, 600, 0), (64, 2400, 1), (120, 5000, 2)])
+def test_staged_pricing_takes_the_reference_decisions(m, n, seed, monkeypatch):
+    """Staged pricing of the primal revised loop (large A: first eighth of the columns, the rest only when that prefix
+    cannot settle primal_solvers.py:135-142).  Forced on for small problems here: the full solve -- early iterations
+    resolve in the prefix, the last ones need the whole row -- must give the oracle's pivot sequence, and the same
+    B^-1 / x / cost bit for bit as the unstaged chain."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(m, n, seed)
+    want = O.OracleRevised(c, A, b, basis, log_cap=20000).solve(100000)
+    assert want.status == O.OPTIMAL
+    cls = logged(PrimalRevisedSimplexSolver, cap=20000)
+    monkeypatch.setenv("LPX_STAGED_MIN_MB", "0")
+    s1 = cls(c, A, b, basis)
+    r1 = s1.solve(100000)
+    assert s1.pivot_log().tolist() == want.log.tolist()
+    assert r1.optimum and r1.iters == want.iters
+    assert_close(r1.x, want.x, "x")
+    monkeypatch.setenv("LPX_STAGED_PRICING", "0")
+    s0 = cls(c, A, b, basis)
+    r0 = s0.solve(100000)
+    assert s0.pivot_log().tolist() == s1.pivot_log().tolist()
+    assert np.array_equal(r0.x, r1.x) and r0.cost == r1.cost
+    assert np.array_equal(s0.inv_basis_matrix, s1.inv_basis_matrix)
+
+
 def test_refine_every_keeps_a_long_run_exact():
     """Opt-in periodic refinement inside solve() (engine.refine_every): the full Bland solve of gen_primal(256, 512, 0)
     (3470 pivots in the reference) still ends on the reference's optimum, and the final inverse is exact to 1e-12."""
