@@ -199,6 +199,14 @@ int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, int rescan, void 
 /* Part 2, after an all-gather of the proposals (recvbuf = nranks consecutive messages): pick the global
  * entering column (lowest index), run the ratio test on the replicated x_B column, update the local slice. */
 int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);
+/* The same step split in two so that the all-gather of pivot t+1 can overlap the update of pivot t (same reference
+ * lines as lpx_tableau_commit: primal_solvers.py:135-167, :247-253).  commit_begin = entering/leaving decision and eta
+ * column of this pivot and, when sendbuf_next != NULL, this rank's proposal for the NEXT pivot, formed from the old
+ * tableau, e and the old pivot row exactly as the update will write them; commit_update = the rank-1 update.  The host
+ * starts an asynchronous all-gather of sendbuf_next between the two calls. */
+int lpx_tableau_commit_begin(const lpx_tableau *s, const double *recvbuf, int64_t nranks, double *sendbuf_next,
+                             void *stream);
+int lpx_tableau_commit_update(const lpx_tableau *s, void *stream);
 /* x[n_global-sized on rank owning..] : x_B and basis are replicated, so every rank can expand: x, cost. */
 int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
 

@@ -80,6 +80,8 @@ _SIGS = {
     "lpx_tableau_msg_len": (i64, [i64]),
     "lpx_tableau_propose": (C.c_int, [C.POINTER(LpxTableau), vp, C.c_int, vp]),
     "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
+    "lpx_tableau_commit_begin": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp, vp]),
+    "lpx_tableau_commit_update": (C.c_int, [C.POINTER(LpxTableau), vp]),
     "lpx_refine_workspace_bytes": (i64, [i64]),
     "lpx_revised_refine": (C.c_int, [C.POINTER(LpxRevised), i64, C.c_int, vp, i64, vp, vp]),
     "lpx_invert_workspace_bytes": (i64, [i64]),

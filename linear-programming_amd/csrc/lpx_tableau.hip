@@ -425,12 +425,12 @@ static inline int64_t t_prep_len(const lpx_tableau *s)
     const int64_t a = lpx_roundup(s->n + 1, 2), b = s->m + 1;
     return a > b ? a : b;
 }
-static void t_launch_update(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st)
+static void t_launch_update(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st, bool price = true)
 {
     Rank1Args a{};
     a.M = s->T; a.rows = s->m + 1; a.cols = s->n + 1; a.ld = s->ld; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
-    a.price_v0 = w.price.v0; a.price_i0 = w.price.i0; a.pricing = (int)s->pricing;
+    a.price_v0 = price ? w.price.v0 : nullptr; a.price_i0 = price ? w.price.i0 : nullptr; a.pricing = (int)s->pricing;
     lpx_k1_begin(st);
     lpx_rank1_launch<true>(p, a, st);
     lpx_k1_end(st);
@@ -514,6 +514,122 @@ extern "C" int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, i
                            nrow, (const double *)w.d, w.e, w.rowr);
     }
     t_launch_update(s, w, plan, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Column-partitioned loop with the exchange of pivot t+1 overlapped with the update of pivot t ("lookahead").
+// Once pivot t's leaving row is known (e, rowr are set), the NEXT proposal of a rank needs only two thin pieces of the
+// updated tableau: its reduced-cost row (to find the next local entering candidate) and that candidate's column.  Both
+// are formed from the old T, e and rowr with K1's own expressions -- bit for bit what K1 is about to write -- so the
+// all-gather of pivot t+1 can travel over xGMI while K1 streams the slice through HBM:
+//     commit_begin(recv_t, send_t+1): select, prepare, price_next, propose_next      (stream s)
+//     all-gather(send_t+1 -> recv_t+1), asynchronous                                  (RCCL's stream, after propose_next)
+//     commit_update: K1                                                               (stream s, concurrent with it)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s)
+{
+    const int64_t u = s.ctrl->enter_j - s.col0;
+    return (u < 0 || u >= s.n) ? -1 : u;
+}
+// per-strip pricing partials of the reduced-cost row as K1 will leave it (layout of k_t_price / K1's epilogue)
+__global__ __launch_bounds__(LPX_BLOCK) void k_t_price_next(lpx_tableau s, Partials P, int64_t strip, const double *e,
+                                                           const double *rowr)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t unit = t_unit_col(s);
+    const double em = e[s.m];
+    const int64_t c0 = (int64_t)blockIdx.x * strip;
+    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    double mn = LPX_INF;
+    int64_t jn = LPX_NOIDX;
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
+        const double rc = (j == unit) ? 0.0 : fma(em, rowr[j], s.T[s.m * s.ld + j]);
+        if (s.pricing == LPX_PRICE_DANTZIG) {
+            if (vi_less(rc, s.col0 + j, mn, jn)) { mn = rc; jn = s.col0 + j; }
+        } else {
+            mn = fmin(mn, rc);
+            if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+        }
+    }
+    if (s.pricing == LPX_PRICE_DANTZIG) {
+        const VI t = block_argmin(VI{mn, jn}, red);
+        mn = t.v;
+        jn = t.i;
+    } else {
+        mn = block_min(mn, red);
+        jn = block_imin(jn, red);
+    }
+    if (threadIdx.x == 0) {
+        P.v0[blockIdx.x] = mn;
+        P.i0[blockIdx.x] = jn;
+    }
+}
+// the proposal for the next pivot: (min rc, first owned negative column, that column) of the tableau after K1
+__global__ __launch_bounds__(LPX_BLOCK) void k_t_propose_next(lpx_tableau s, Partials P, int64_t nprice, const double *e,
+                                                             const double *rowr, double *sendbuf)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    double mn;
+    int64_t j;
+    combine_price(s.pricing, P, nprice, red, mn, j);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sendbuf[0] = mn;
+        sendbuf[1] = (double)j;
+    }
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (i > s.m) return;
+    double v = 0.0;
+    if (j != LPX_NOIDX) {
+        const int64_t jl = j - s.col0, r = s.ctrl->leave_r;
+        if (jl == t_unit_col(s)) v = (i == r) ? 1.0 : 0.0;
+        else v = (i == r) ? e[i] * rowr[jl] : fma(e[i], rowr[jl], s.T[i * s.ld + jl]);
+    }
+    sendbuf[2 + i] = v;
+}
+
+// select + prepare from the gathered proposals of this pivot; sendbuf_next != NULL: also this rank's proposal for the
+// next pivot.  The update itself is lpx_tableau_commit_update.
+extern "C" int lpx_tableau_commit_begin(const lpx_tableau *s, const double *recvbuf, int64_t nranks, double *sendbuf_next,
+                                        void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    const int64_t nrow = lpx_cdiv(s->m + 1, LPX_BLOCK), msg = lpx_tableau_msg_len(s->m);
+    if (t_is_small(s)) {
+        hipLaunchKernelGGL((k_t_pre_small<true>), dim3(1), dim3(T_SMALL_THREADS), 0, st, *s, w.price, (int64_t)0, recvbuf, nranks, msg,
+                           w.d, w.e, w.rowr);
+    } else {
+        hipLaunchKernelGGL(k_t_select, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks, msg, w.ratio, w.d);
+        hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.ratio,
+                           nrow, (const double *)w.d, w.e, w.rowr);
+    }
+    if (sendbuf_next != nullptr) {
+        const int64_t strip = 2 * (int64_t)plan.threads * plan.vpt;
+        hipLaunchKernelGGL(k_t_price_next, dim3(plan.grid.x), dim3(LPX_BLOCK), 0, st, *s, w.price, strip, (const double *)w.e,
+                           (const double *)w.rowr);
+        hipLaunchKernelGGL(k_t_propose_next, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.price, (int64_t)plan.grid.x,
+                           (const double *)w.e, (const double *)w.rowr, sendbuf_next);
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_commit_update(const lpx_tableau *s, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    // the pricing partials of the next pivot exist already (k_t_price_next) or are rescanned by lpx_tableau_propose
+    t_launch_update(s, w, plan, (hipStream_t)stream, false);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

@@ -9,6 +9,7 @@ plus a replica of the x_B column.  Each pivot needs ONE collective: an all-gathe
 (local min rc, first owned negative column, that column of T) -- ``lpx_tableau_msg_len(m)`` doubles per rank.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -48,19 +49,32 @@ class ProposalExchange:
         self.torch, self.dist, self.group = torch, dist, group
         self.nranks = dist.get_world_size(group)
         self.msg = int(msg_len)
-        self.sendbuf = torch.zeros(self.msg, dtype=torch.float64, device=device)
-        self.recvbuf = torch.zeros(self.msg * self.nranks, dtype=torch.float64, device=device)
+        # two slots: with lookahead the proposals of pivot t+1 are gathered while pivot t's are still in use
+        self.sendbufs = [torch.zeros(self.msg, dtype=torch.float64, device=device) for _ in range(2)]
+        self.recvbufs = [torch.zeros(self.msg * self.nranks, dtype=torch.float64, device=device) for _ in range(2)]
+        self.sendbuf, self.recvbuf = self.sendbufs[0], self.recvbufs[0]
         self.staged = dist.get_backend(group) == "gloo" and self.sendbuf.is_cuda
 
-    def all_gather(self):
+    def all_gather(self, slot=0):
+        self.wait(self.all_gather_async(slot))
+        return self.recvbufs[slot]
+
+    def all_gather_async(self, slot):
+        """Start the all-gather of slot `slot`; returns a handle for wait() (None: already complete).  With the nccl
+        backend the collective is ordered after the work already enqueued on the current stream and runs beside what
+        is enqueued next; wait() makes the current stream (not the host) wait for it."""
+        send, recv = self.sendbufs[slot], self.recvbufs[slot]
         if self.staged:
-            send = self.sendbuf.cpu()
-            recv = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
-            self.dist.all_gather_into_tensor(recv, send, group=self.group)
-            self.recvbuf.copy_(recv)
-        else:
-            self.dist.all_gather_into_tensor(self.recvbuf, self.sendbuf, group=self.group)
-        return self.recvbuf
+            host = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            recv.copy_(host)
+            return None
+        return self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+
+    @staticmethod
+    def wait(work):
+        if work is not None:
+            work.wait()
 
 
 class TableauEngine:
@@ -68,6 +82,8 @@ class TableauEngine:
 
     CHUNK = 64
     FIRST_CHUNK = 16
+    #: column-partitioned primal loop: overlap the exchange of pivot t+1 with the update of pivot t
+    LOOKAHEAD = os.environ.get("LPX_TABLEAU_LOOKAHEAD", "1") != "0"
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
                  group=None, pricing="first_negative", dual=False):
@@ -164,12 +180,31 @@ class TableauEngine:
                 ex.all_gather()
                 _lib.check(self.lib.lpx_tableau_dual_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
             return
-        for it in range(int(iters)):
-            # the update kernel of the previous pivot leaves the pricing partials behind; only the first pivot of a
-            # call rescans the reduced-cost row (the caller may have touched T in between)
-            _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbuf.data_ptr(), int(it == 0), st))
-            ex.all_gather()
-            _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
+        iters = int(iters)
+        if not self.LOOKAHEAD:
+            for it in range(iters):
+                # the update kernel of the previous pivot leaves the pricing partials behind; only the first pivot of a
+                # call rescans the reduced-cost row (the caller may have touched T in between)
+                _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbuf.data_ptr(), int(it == 0), st))
+                ex.all_gather()
+                _lib.check(self.lib.lpx_tableau_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
+            return
+        # lookahead: the proposal of pivot t+1 is formed before pivot t's update is launched, and its all-gather
+        # travels while the update runs (lpx_tableau_commit_begin / _update)
+        if iters <= 0:
+            return
+        cur = 0
+        _lib.check(self.lib.lpx_tableau_propose(C.byref(self.s), ex.sendbufs[cur].data_ptr(), 1, st))
+        ex.all_gather(cur)
+        for it in range(iters):
+            nxt = cur ^ 1
+            last = it + 1 == iters
+            _lib.check(self.lib.lpx_tableau_commit_begin(C.byref(self.s), ex.recvbufs[cur].data_ptr(), self.nranks,
+                                                         None if last else ex.sendbufs[nxt].data_ptr(), st))
+            work = None if last else ex.all_gather_async(nxt)
+            _lib.check(self.lib.lpx_tableau_commit_update(C.byref(self.s), st))
+            ex.wait(work)
+            cur = nxt
 
     def run(self, maxiters):
         st = stream_ptr()

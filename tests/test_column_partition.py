@@ -17,11 +17,11 @@ def _free_port():
     return p
 
 
-def _run(mode, nproc, m, n, seed, maxiters):
+def _run(mode, nproc, m, n, seed, maxiters, **extra_env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_colpart_worker.py"), mode, str(m), str(n), str(seed), str(maxiters)]
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **extra_env)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count(" ok") == nproc
@@ -36,6 +36,17 @@ def test_protocol_cpu_gloo(nproc, m, n):
 @pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
 def test_product_path_two_ranks_one_gpu(nproc, m, n):
     _run("gpu", nproc, m, n, 2, 100000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"LPX_TABLEAU_SMALL": "0"}, {"LPX_TABLEAU_LOOKAHEAD": "0"},
+                                 {"LPX_TABLEAU_SMALL": "0", "LPX_TABLEAU_LOOKAHEAD": "0"}],
+                         ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
+def test_product_path_lookahead_and_kernel_variants(env):
+    """The default run above overlaps the exchange of pivot t+1 with the update of pivot t (lpx_tableau_commit_begin /
+    _update) behind the single-workgroup prologue; here the multi-workgroup select/prepare chain with lookahead, and both
+    chains with the plain propose -> all-gather -> commit loop.  All must give the oracle's pivot sequence."""
+    _run("gpu", 2, 64, 128, 2, 100000, **env)
 
 
 @pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
