@@ -1124,12 +1124,13 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
     struct {
         lpx_revised s;
         int kind, vpt, unroll, nt, threads, fuse;
-        int64_t rpb;
+        int64_t rpb, n1, ych, ach; // everything the captured launches depend on besides the state itself
     } key;
     memset(&key, 0, sizeof key);
     const Rank1Plan plan = lpx_rank1_plan(s->m, s->m);
     key.s = sv; key.kind = kind; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt;
     key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse + 2 * staged;
+    key.n1 = w.n1; key.ych = w.py.nch; key.ach = w.pa.nch;
     if (iters <= 0) return LPX_OK;
     if (fuse) launch_colsum_B(sp, w, st0);
     return lpx_run_iterations(&key, sizeof key, iters, st0, one);

@@ -149,3 +149,51 @@ def test_tableau_beyond_32bit_element_indices():
     assert worst <= 1e-12, worst
     # the last rows / columns (offsets > 2^32) were really written
     assert float((T[m, :n] - ref[m, :n]).abs().max()) <= 1e-12 and bool((T[:, log[-1][1]] != 0).sum() == 1)
+
+
+def test_revised_form_10000x20000_invariants():
+    """The revised loop at the size where its large-matrix paths engage (non-temporal streams, K1 fused with the next y
+    pass, staged pricing): after 60 pivots B^-1 is the inverse of the current basis matrix, x_B = B^-1 b >= 0, the cost
+    never rose, A x = b; the tableau-form engine takes the same 60 pivots on the same data and the oracle the same
+    first 6 (m = 10000: a quarter of a second per oracle pivot)."""
+    import torch
+
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    m, n, K = 10000, 20000, 60
+    A, b, c, basis = gen.gen_primal_columns(m, n, 0, 0, n)
+    cls = type("L", (PrimalRevisedSimplexSolver,), {"_LOG_CAP": K + 1})
+    s = cls(c, A, b, basis)
+    costs = []
+    for k in (20, 20, 20):
+        res = s.solve(k)
+        costs.append(float(res.cost))
+        assert res.iters == k and res.optimum is False
+    assert costs[0] >= costs[1] >= costs[2] and costs[2] < 0
+    log = s.pivot_log()
+    assert len(log) == K
+    eng = s._engine
+    bas = torch.from_numpy(res.basis).cuda()
+    A_dev = torch.from_numpy(A).cuda()
+    Bm = A_dev[:, bas].to(torch.float64)
+    Binv = eng.Binv[:, :m]
+    resid = Bm @ Binv
+    resid.diagonal().sub_(1.0)
+    assert float(resid.abs().max()) < 1e-10
+    xB = eng.xB[:m]
+    want = Binv @ torch.from_numpy(b.astype(np.float64)).cuda()
+    assert float((xB - want).abs().max()) < 1e-9 and float(xB.min()) >= 0.0
+    x = res.x
+    nz = np.flatnonzero(x)
+    assert np.abs(A[:, nz].astype(np.float64) @ x[nz] - b.astype(np.float64)).max() < 1e-9
+    assert abs(float(np.dot(c.astype(np.float64), x)) - res.cost) <= 1e-9 * max(1.0, abs(res.cost))
+    del resid, Bm, A_dev
+    tcls = type("LT", (PrimalTableauSimplexSolver,), {"_LOG_CAP": K + 1})
+    t = tcls(c, A, b, basis, columns=(0, n), n_global=n)
+    rt = t.solve(K)
+    assert t.pivot_log().tolist() == log.tolist()
+    assert abs(rt.cost - res.cost) <= 1e-9 * max(1.0, abs(res.cost))
+    o = O.OracleRevised(c, A, b, basis, log_cap=8).solve(6)
+    assert o.log.tolist() == log[:6].tolist()
