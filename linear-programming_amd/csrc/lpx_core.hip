@@ -90,7 +90,7 @@ static inline ColsumPlan colsum_plan(int64_t rows, int64_t cols, int V, int64_t 
     p.threads = LPX_BLOCK;
     while (p.threads > 64 && lpx_cdiv(cols, (int64_t)p.threads * V) * 32 < 512) p.threads /= 2;
     p.nstrips = lpx_cdiv(cols, (int64_t)p.threads * V);
-    int64_t nch = lpx_cdiv(480, p.nstrips);
+    int64_t nch = lpx_cdiv(480 * (LPX_BLOCK / p.threads), p.nstrips); // ~2 x 4 waves per CU whatever the width
     const int64_t maxch = lpx_env_int("LPX_COLSUM_MAXCH", (int)maxch_dflt);
     if (nch > maxch) nch = maxch;
     if (nch < 1) nch = 1;
