@@ -236,6 +236,9 @@ struct ColsumArgs {
     const double *gate_v0;
     const int64_t *gate_i0;
     int64_t gate_n;
+    // dual loop: a second weighted column sum in the same pass over M, part2[chunk][k] = sum_i B^-1[r][i] * M[i][k]
+    // (the dual row, dual_solvers.py:37-38), r = ctrl->leave_r; needs lds_weights (2 * rpc * 8 bytes)
+    double *part2;
 };
 
 // primal_solvers.py:135-142 needs two facts about rc: the first index with rc_j < 0 and whether min(rc) passes the
@@ -288,7 +291,7 @@ __device__ __forceinline__ VecT lpx_stream_load(const VecT *p)
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
-template <typename MatT, typename AccT, int V, bool NT>
+template <typename MatT, typename AccT, int V, bool NT, bool TWO = false>
 __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
 {
     typedef MatT vec_t __attribute__((ext_vector_type(V)));
@@ -304,13 +307,17 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
         const int64_t rr = (a.wmode == W_BINV_ROW) ? a.ctrl->leave_r : 0;
         for (int64_t i = row0 + threadIdx.x; i < row1; i += blockDim.x)
             wl[i - row0] = (a.wmode == W_YPART) ? fin_sum<AccT>(a.ypart, a.ynch, a.yld, i) : colsum_weight<AccT>(a, i, rr);
+        if (TWO) {
+            const int64_t r2 = a.ctrl->leave_r;
+            for (int64_t i = row0 + threadIdx.x; i < row1; i += blockDim.x) wl[a.rpc + i - row0] = (AccT)a.Binv[r2 * a.ldB + i];
+        }
         __syncthreads();
     }
     if (col >= a.cols) return;
     const int64_t r = (a.wmode == W_BINV_ROW) ? a.ctrl->leave_r : 0;
-    AccT acc[V];
+    AccT acc[V], acc2[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = (AccT)0;
+    for (int v = 0; v < V; ++v) acc[v] = acc2[v] = (AccT)0;
     const MatT *p = (const MatT *)a.M + row0 * a.ld + col;
     int64_t i = row0;
     for (; i + 4 <= row1; i += 4) {
@@ -332,6 +339,17 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
             acc[v] = fma(w2, (AccT)x2[v], acc[v]);
             acc[v] = fma(w3, (AccT)x3[v], acc[v]);
         }
+        if (TWO) {
+            const AccT u0 = wl[a.rpc + i - row0], u1 = wl[a.rpc + i + 1 - row0], u2 = wl[a.rpc + i + 2 - row0],
+                       u3 = wl[a.rpc + i + 3 - row0];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                acc2[v] = fma(u0, (AccT)x0[v], acc2[v]);
+                acc2[v] = fma(u1, (AccT)x1[v], acc2[v]);
+                acc2[v] = fma(u2, (AccT)x2[v], acc2[v]);
+                acc2[v] = fma(u3, (AccT)x3[v], acc2[v]);
+            }
+        }
         p += 4 * a.ld;
     }
     for (; i < row1; ++i) {
@@ -339,12 +357,23 @@ __device__ __forceinline__ void colsum_body(const ColsumArgs &a)
         const AccT w0 = lds_w ? wl[i - row0] : colsum_weight<AccT>(a, i, r);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = fma(w0, (AccT)x0[v], acc[v]);
+        if (TWO) {
+            const AccT u0 = wl[a.rpc + i - row0];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc2[v] = fma(u0, (AccT)x0[v], acc2[v]);
+        }
         p += a.ld;
     }
     double *out = a.part + (int64_t)blockIdx.y * a.ldp + col;
 #pragma unroll
     for (int v = 0; v < V; ++v)
         if (col + v < a.cols) out[v] = (double)acc[v];
+    if (TWO) {
+        double *out2 = a.part2 + (int64_t)blockIdx.y * a.ldp + col;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (col + v < a.cols) out2[v] = (double)acc2[v];
+    }
 }
 
 template <typename MatT, int V>
@@ -354,6 +383,12 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_colsum(ColsumArgs a)
     if (a.gate_n > 0) {
         __shared__ BlockRed red;
         if (pricing_resolved(a.gate_v0, a.gate_i0, a.gate_n, red)) return;
+    }
+    if (a.part2 != nullptr) { // dual loop: z and the dual row in one pass
+        if (a.ctrl->f32_phase) colsum_body<MatT, float, V, false, true>(a);
+        else if (a.nt) colsum_body<MatT, double, V, true, true>(a);
+        else colsum_body<MatT, double, V, false, true>(a);
+        return;
     }
     if (a.ctrl->f32_phase) colsum_body<MatT, float, V, false>(a); // first iteration only
     else if (a.nt) colsum_body<MatT, double, V, true>(a);
@@ -925,7 +960,7 @@ static void launch_colsum_B(const lpx_revised *s, const RevisedWs &w, hipStream_
 }
 // columns [col0, col0 + cols) of A with plan p; gate_n > 0: skipped when the first gate_n pricing partials decide
 static void launch_colsum_A_range(const lpx_revised *s, const RevisedWs &w, const ColsumPlan &p, int wmode, double *part,
-                                  int64_t col0, int64_t cols, int64_t gate_n, hipStream_t st)
+                                  int64_t col0, int64_t cols, int64_t gate_n, hipStream_t st, double *part2 = nullptr)
 {
     ColsumArgs a{};
     a.M = s->A + col0; a.ld = s->ldA; a.rows = s->m; a.cols = cols; a.rpc = p.rpc;
@@ -933,10 +968,17 @@ static void launch_colsum_A_range(const lpx_revised *s, const RevisedWs &w, cons
     a.part = part; a.ldp = w.ldzp; a.ctrl = s->ctrl;
     a.ypart = w.ypart; a.ynch = w.py.nch; a.yld = w.ldyp;
     a.gate_v0 = w.price.v0; a.gate_i0 = w.price.i0; a.gate_n = gate_n;
-    const size_t lds = colsum_lds_bytes(p.rpc);
+    size_t lds = colsum_lds_bytes(p.rpc);
     a.lds_weights = lds != 0;
+    a.part2 = part2;
+    if (part2 != nullptr) lds *= 2; // callers check revised_dual_one_pass
     a.nt = lpx_stream_nt(4 * s->m * s->ldA);
     hipLaunchKernelGGL((k_colsum<float, 4>), dim3((unsigned)p.nstrips, (unsigned)p.nch), dim3(p.threads), lds, st, a);
+}
+// dual loop: z = y A and the dual row B^-1[r,:] A from one pass over A (weights of both in LDS)
+static inline bool revised_dual_one_pass(const RevisedWs &w)
+{
+    return lpx_env_int("LPX_DUAL_ONE_PASS", 1) != 0 && colsum_lds_bytes(w.pa.rpc) != 0 && 2 * w.pa.rpc * 8 <= 48 * 1024;
 }
 static void launch_colsum_A(const lpx_revised *s, const RevisedWs &w, int wmode, double *part, hipStream_t st)
 {
@@ -1032,6 +1074,7 @@ static void launch_update_y(const lpx_revised *s, const RevisedWs &w, bool updat
     const dim3 grid((unsigned)w.py.nstrips, (unsigned)w.py.nch);
     const size_t lds = colsum_lds_bytes(w.py.rpc);
     lpx_k1_begin(st);
+    // unroll 2 / 4 / 8 and non-temporal loads / stores / both are within 3 % of each other at m = 10000
     if (lpx_stream_nt(8 * s->m * s->ldB)) hipLaunchKernelGGL((k_rank1_y<1, 4>), grid, dim3(w.py.threads), lds, st, a, f);
     else hipLaunchKernelGGL((k_rank1_y<0, 4>), grid, dim3(w.py.threads), lds, st, a, f);
     lpx_k1_end(st);
@@ -1105,8 +1148,12 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
             update(true, st);
         } else if (kind == LPX_KIND_DUAL) {
             hipLaunchKernelGGL(k_dual_select, dim3(1), dim3(LPX_BLOCK), 0, st, (const double *)sp->xB, sp->m, sp->ctrl);
-            launch_colsum_A(sp, w, W_BINV_ROW, w.zpart2, st);
-            sums(st);
+            if (fuse && revised_dual_one_pass(w)) {
+                launch_colsum_A_range(sp, w, w.pa, W_YPART, w.zpart, 0, sp->n, 0, st, w.zpart2);
+            } else {
+                launch_colsum_A(sp, w, W_BINV_ROW, w.zpart2, st);
+                sums(st);
+            }
             launch_fin(sp, w, FIN_DUAL, nullptr, st);
             launch_direction(sp, w, DIR_DUAL, -1, st);
             launch_prepare(sp, w, PREP_DUAL, -1, st);
@@ -1129,7 +1176,7 @@ extern "C" int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters
     memset(&key, 0, sizeof key);
     const Rank1Plan plan = lpx_rank1_plan(s->m, s->m);
     key.s = sv; key.kind = kind; key.vpt = plan.vpt; key.unroll = plan.unroll; key.nt = plan.nt;
-    key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse + 2 * staged;
+    key.threads = plan.threads; key.rpb = plan.rows_per_block; key.fuse = fuse + 2 * staged + 4 * (int)revised_dual_one_pass(w);
     key.n1 = w.n1; key.ych = w.py.nch; key.ach = w.pa.nch;
     if (iters <= 0) return LPX_OK;
     if (fuse) launch_colsum_B(sp, w, st0);
