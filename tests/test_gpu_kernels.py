@@ -172,7 +172,7 @@ def _dinverse(env, A, ldi_pad=0):
     return out.cpu().numpy()[:, :m], int(info.item())
 
 
-@pytest.mark.parametrize("m", [1, 2, 5, 63, 64, 65, 128, 130, 200, 1000])
+@pytest.mark.parametrize("m", [1, 2, 5, 63, 64, 65, 128, 130, 200, 1000, 2100])
 def test_dinverse_blocked_gauss_jordan_vs_numpy(env, m):
     """lpx_dinverse (blocked Gauss-Jordan, partial pivoting, MFMA trailing updates) against np.linalg.inv: block edges at
     64, ragged last block, strided output.  Floating point: residual |A X - I| <= 1e-13 * m * cond-ish factor and
