@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "config5"])
+    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "config5"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -240,7 +240,7 @@ def bench_revised(args):
     from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
     from oracle import oracle as O
 
-    m, n = (1000, 2000) if args.workload == "revised1k" else (10000, 20000)
+    m, n = {"revised1k": (1000, 2000), "revised10k": (10000, 20000), "revised20k": (20000, 40000)}[args.workload]
     K, W = args.steps, args.warmup
     A, b, c, basis = problems.gen_primal_columns(m, n, args.seed, 0, n)
     Solver = type("BenchRevised", (PrimalRevisedSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
@@ -264,7 +264,7 @@ def bench_revised(args):
     ctrl = eng.read_ctrl()
     if ctrl.pivots != W + K + extra or ctrl.status != _lib.RUNNING:
         sys.exit(f"bench invalid: {ctrl.pivots} pivots, status {ctrl.status}")
-    kc = args.cpu_pivots if args.cpu_pivots is not None else (300 if m <= 1000 else 20)
+    kc = args.cpu_pivots if args.cpu_pivots is not None else (300 if m <= 1000 else 20 if m <= 10000 else 6)
     cpu = None
     if kc > 0:
         o = O.OracleRevised(c, A, b, basis, log_cap=kc + 1)
