@@ -102,7 +102,11 @@ def main():
 
     m, n = (20000, 40000) if args.workload == "tableau" else (1000, 2000)
     K, W = args.steps, args.warmup
-    j0, j1 = n * rank // world, n * (rank + 1) // world
+    # the tableau carries the nonbasic columns only (condensed form): with the slack starting basis these are the n - m
+    # structural columns, partitioned evenly over the ranks; LPX_TABLEAU_CONDENSED=0: every column, n / world per rank
+    condensed = PrimalTableauSimplexSolver.CONDENSED
+    ncarry = n - m if condensed else n
+    j0, j1 = ncarry * rank // world, ncarry * (rank + 1) // world
     t_setup = time.time()
     A_cols, b, c, basis = problems.gen_primal_columns(m, n, args.seed, j0, j1)
     Solver = type("BenchTableau", (PrimalTableauSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
@@ -160,7 +164,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
     if os.path.exists(tpath) and args.workload == "tableau" and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath))
+            # the PMC figure belongs to one layout: use it only for the layout it was measured on
+            if 0.9 * bytes_per_launch <= rec.get("hbm_bytes_per_launch", 0) <= 1.2 * bytes_per_launch:
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -179,17 +186,21 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"gen_primal_columns(m={m}, n={n}, seed={args.seed}) dense primal tableau simplex, "
                                f"slack start, first-negative-index pricing",
-                   "m": m, "n": n, "form": "tableau", "partition": f"columns/{world}",
+                   "m": m, "n": n,
+                   "form": "condensed tableau: (m+1) x (n-m+1), the nonbasic columns and x_B (basic columns are unit "
+                           "vectors no pivot changes)" if condensed else "full tableau: (m+1) x (n+1)",
+                   "partition": f"columns/{world}",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1_avg_s * 1e3, "launches": k1_n.value,
                      "k1_timing": "HIP events in the timed region" if events_in_timed
                      else "HIP events in a separate eager pass (timed region replays hipGraphs)",
-                     "whole_pivot_GBs": 16.0 * (m + 1) * (n + 1) * K / dt / 1e9},
+                     "whole_pivot_GBs": 16.0 * (m + 1) * (ncarry + 1) * K / dt / 1e9},
     }
     if rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args, m, n, A_cols, b, c, basis, solver)
+        A_full = A_cols if not condensed else problems.gen_primal_columns(m, n, args.seed, 0, n)[0]
+        out["cpu_baseline"] = cpu_baseline(args, m, n, A_full, b, c, basis, solver)
     elif rank == 0:
         # N>1: rank 0 regenerates the whole matrix and checks the partitioned run's first pivots against the oracle
         full = problems.gen_primal_columns(m, n, args.seed, 0, n)

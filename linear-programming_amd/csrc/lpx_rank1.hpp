@@ -29,6 +29,10 @@ struct Rank1Args {
     double *price_v0;
     int64_t *price_i0;
     int pricing;           // LPX_PRICE_FIRST_NEGATIVE: i0 = first column with rc<0 ; LPX_PRICE_DANTZIG: i0 = argmin rc
+    // condensed tableau (nonbasic columns only, lpx_tableau.hip): variable of each column slot and its inverse map; the
+    // slot handed to the leaving variable is rewritten with the eta column instead of a unit vector
+    const int64_t *slot_var;
+    const int64_t *var_slot;
 };
 
 template <int NT>
@@ -56,11 +60,16 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
         if (TABLEAU) {
             // local index of the entering column; another rank's column (column partition) must not alias the
             // x_B column at local index cols-1
-            unit_col = a.ctrl->enter_j - a.col0;
-            if (unit_col < 0 || unit_col >= a.cols - 1) unit_col = -1;
+            if (a.var_slot) {
+                unit_col = a.var_slot[a.ctrl->leave_var]; // k_t_prepare has handed the slot over already
+            } else {
+                unit_col = a.ctrl->enter_j - a.col0;
+                if (unit_col < 0 || unit_col >= a.cols - 1) unit_col = -1;
+            }
         }
     }
     const int nthr = blockDim.x;
+    const bool cond = TABLEAU && a.var_slot != nullptr;
     const int64_t row0 = (int64_t)blockIdx.y * a.rows_per_block;
     const int64_t row1 = (row0 + a.rows_per_block < a.rows) ? row0 + a.rows_per_block : a.rows;
     const double *__restrict__ e = a.e;
@@ -115,8 +124,8 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
                     x[u][v][0] = fma(ei, pr[v][0], x[u][v][0]);
                     x[u][v][1] = fma(ei, pr[v][1], x[u][v][1]);
                 }
-                if (fix0[v]) x[u][v][0] = isr ? 1.0 : 0.0;
-                if (fix1[v]) x[u][v][1] = isr ? 1.0 : 0.0;
+                if (fix0[v]) x[u][v][0] = cond ? ei : (isr ? 1.0 : 0.0);
+                if (fix1[v]) x[u][v][1] = cond ? ei : (isr ? 1.0 : 0.0);
                 if (TABLEAU && (i + u) == lastrow) lastv[v] = x[u][v];
             }
         }
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
                 x0[0] = fma(ei, pr[v][0], x0[0]);
                 x0[1] = fma(ei, pr[v][1], x0[1]);
             }
-            if (fix0[v]) x0[0] = isr ? 1.0 : 0.0;
-            if (fix1[v]) x0[1] = isr ? 1.0 : 0.0;
+            if (fix0[v]) x0[0] = cond ? ei : (isr ? 1.0 : 0.0);
+            if (fix1[v]) x0[1] = cond ? ei : (isr ? 1.0 : 0.0);
             if (TABLEAU && i == lastrow) lastv[v] = x0;
             lpx_st2<NT>(p + v * (2 * nthr), x0);
         }
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
             for (int q = 0; q < 2; ++q) {
                 if (col + q < nstruct) {
                     const double rc = lastv[v][q];
-                    const int64_t gj = a.col0 + col + q;
+                    const int64_t gj = a.slot_var ? a.slot_var[col + q] : a.col0 + col + q;
                     if (a.pricing == LPX_PRICE_DANTZIG) {
                         if (vi_less(rc, gj, mn, jn)) { mn = rc; jn = gj; }
                     } else {

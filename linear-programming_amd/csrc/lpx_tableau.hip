@@ -62,9 +62,47 @@ static int check_tableau(const lpx_tableau *s)
     LPX_REQUIRE(s->workspace_bytes >= lpx_tableau_workspace_bytes(s->m, s->n), "workspace too small");
     LPX_REQUIRE(lpx_cdiv(s->n, LPX_BLOCK) <= LPX_MAXP && lpx_cdiv(s->m + 1, LPX_BLOCK) <= LPX_MAXP,
                 "problem too large for the partial arrays");
-    LPX_REQUIRE(s->col0 >= 0 && s->n_global >= s->col0 + s->n, "bad column partition");
+    LPX_REQUIRE((s->slot_var == nullptr) == (s->var_slot == nullptr), "slot_var and var_slot come together");
+    LPX_REQUIRE(s->slot_var != nullptr || (s->col0 >= 0 && s->n_global >= s->col0 + s->n), "bad column partition");
+    LPX_REQUIRE(s->slot_var == nullptr || s->n_global >= s->n, "more slots than variables");
     LPX_REQUIRE(s->pricing == LPX_PRICE_FIRST_NEGATIVE || s->pricing == LPX_PRICE_DANTZIG, "bad pricing rule");
     return LPX_OK;
+}
+
+// Condensed form (slot_var != NULL): T holds only the NONBASIC columns -- a basic column is a unit vector that the
+// rank-1 update leaves untouched (its pivot-row entry is 0), so carrying it costs memory and 16 bytes of HBM traffic per
+// element and pivot for nothing.  Column slot k holds variable slot_var[k]; var_slot[] is the inverse map (-1: not in a
+// slot of this rank).  On a pivot the entering variable's slot takes over the leaving variable, whose column is the eta
+// column e itself (unit vector e_r updated: 0 + e_i * 1), written by K1 where the full form writes the new unit vector.
+__device__ __forceinline__ int64_t t_var(const lpx_tableau &s, int64_t slot) { return s.slot_var ? s.slot_var[slot] : s.col0 + slot; }
+// local column of variable j, -1 if this rank does not hold it
+__device__ __forceinline__ int64_t t_slot(const lpx_tableau &s, int64_t j)
+{
+    if (s.var_slot) return s.var_slot[j];
+    const int64_t k = j - s.col0;
+    return (k < 0 || k >= s.n) ? -1 : k;
+}
+// bookkeeping of a basis change (single thread): the full form flips var_state, the condensed form hands the slot over
+__device__ __forceinline__ void t_swap_columns(const lpx_tableau &s, int64_t j, int64_t leaving)
+{
+    if (s.slot_var) {
+        const int64_t k = s.var_slot[j];
+        if (k >= 0) {
+            s.slot_var[k] = leaving;
+            s.var_slot[leaving] = k;
+        }
+        s.var_slot[j] = -1;
+        return;
+    }
+    const int64_t ll = leaving - s.col0, jl = j - s.col0;
+    if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
+    if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+}
+// after the bookkeeping of this pivot: the local column that the update rewrites as a whole (full form: the entering
+// variable's, which becomes a unit vector; condensed: the slot that now belongs to the leaving variable), -1 if none here
+__device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s)
+{
+    return t_slot(s, s.slot_var ? s.ctrl->leave_var : s.ctrl->enter_j);
 }
 
 // K3 (tableau): scan the carried reduced-cost row: one partial (min rc, first global column with rc<0) per
@@ -80,10 +118,10 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
         const double rc = s.T[s.m * s.ld + j];
         if (s.pricing == LPX_PRICE_DANTZIG) {
-            if (vi_less(rc, s.col0 + j, mn, jn)) { mn = rc; jn = s.col0 + j; }
+            if (vi_less(rc, t_var(s, j), mn, jn)) { mn = rc; jn = t_var(s, j); }
         } else {
             mn = fmin(mn, rc);
-            if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+            if (rc < 0.0 && t_var(s, j) < jn) jn = t_var(s, j);
         }
     }
     if (s.pricing == LPX_PRICE_DANTZIG) {
@@ -150,7 +188,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_column(lpx_tableau s, Partials 
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
     double di = 0.0;
     if (i <= s.m) {
-        di = s.T[i * s.ld + (j - s.col0)];
+        di = s.T[i * s.ld + t_slot(s, j)];
         d[i] = di;
     }
     t_ratio_partial(s, i, di, f32, R, red);
@@ -169,7 +207,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_propose(lpx_tableau s, Partials
         sendbuf[1] = (double)j; // exact: column indices < 2^53, LPX_NOIDX = 2^62
     }
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    if (i <= s.m) sendbuf[2 + i] = (j == LPX_NOIDX) ? 0.0 : s.T[i * s.ld + (j - s.col0)];
+    if (i <= s.m) sendbuf[2 + i] = (j == LPX_NOIDX) ? 0.0 : s.T[i * s.ld + t_slot(s, j)];
 }
 
 // column-partitioned, part 2a: global entering decision from the gathered proposals + ratio partials
@@ -235,9 +273,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_prepare(lpx_tableau s, Partials
     if (lead) {
         const int64_t leaving = s.basis[r];
         s.basis[r] = j;
-        const int64_t ll = leaving - s.col0, jl = j - s.col0;
-        if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
-        if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+        t_swap_columns(s, j, leaving);
         if (s.log && ctrl->pivots < s.log_cap) {
             s.log[3 * ctrl->pivots + 0] = r;
             s.log[3 * ctrl->pivots + 1] = j;
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(T_SMALL_THREADS) void k_t_pre_small(lpx_tableau s, 
     if (opt) return;
 
     // ---- round trip 2: the entering column (d[m] = its reduced cost)
-    const double *src = PART ? recv + win * msg + 2 : s.T + (j - s.col0);
+    const double *src = PART ? recv + win * msg + 2 : s.T + t_slot(s, j);
     const int64_t stride = PART ? 1 : s.ld;
     double dv[T_SMALL_RPT];
     VI best{LPX_INF, LPX_NOIDX};
@@ -395,9 +431,7 @@ __global__ __launch_bounds__(T_SMALL_THREADS) void k_t_pre_small(lpx_tableau s, 
     if (lead) {
         const int64_t leaving = s.basis[r];
         s.basis[r] = j;
-        const int64_t ll = leaving - s.col0, jl = j - s.col0;
-        if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
-        if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+        t_swap_columns(s, j, leaving);
         if (s.log && ctrl->pivots < s.log_cap) {
             s.log[3 * ctrl->pivots + 0] = r;
             s.log[3 * ctrl->pivots + 1] = j;
@@ -430,6 +464,7 @@ static void t_launch_update(const lpx_tableau *s, const TabWs &w, const Rank1Pla
     Rank1Args a{};
     a.M = s->T; a.rows = s->m + 1; a.cols = s->n + 1; a.ld = s->ld; a.e = w.e; a.rowr = w.rowr; a.r = -1;
     a.ctrl = s->ctrl; a.xB = nullptr; a.xr_old = nullptr; a.col0 = s->col0;
+    a.slot_var = s->slot_var; a.var_slot = s->var_slot;
     a.price_v0 = price ? w.price.v0 : nullptr; a.price_i0 = price ? w.price.i0 : nullptr; a.pricing = (int)s->pricing;
     lpx_k1_begin(st);
     lpx_rank1_launch<true>(p, a, st);
@@ -451,7 +486,7 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
 {
     int rc = check_tableau(s);
     if (rc) return rc;
-    LPX_REQUIRE(s->col0 == 0 && s->n_global == s->n, "lpx_tableau_iterate needs an unpartitioned tableau");
+    LPX_REQUIRE(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n), "lpx_tableau_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
@@ -528,11 +563,6 @@ extern "C" int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, i
 //     all-gather(send_t+1 -> recv_t+1), asynchronous                                  (RCCL's stream, after propose_next)
 //     commit_update: K1                                                               (stream s, concurrent with it)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s)
-{
-    const int64_t u = s.ctrl->enter_j - s.col0;
-    return (u < 0 || u >= s.n) ? -1 : u;
-}
 // per-strip pricing partials of the reduced-cost row as K1 will leave it (layout of k_t_price / K1's epilogue)
 __global__ __launch_bounds__(LPX_BLOCK) void k_t_price_next(lpx_tableau s, Partials P, int64_t strip, const double *e,
                                                            const double *rowr)
@@ -546,12 +576,13 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price_next(lpx_tableau s, Parti
     double mn = LPX_INF;
     int64_t jn = LPX_NOIDX;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
-        const double rc = (j == unit) ? 0.0 : fma(em, rowr[j], s.T[s.m * s.ld + j]);
+        // the rewritten column: unit vector (full form, rc 0) or the eta column (condensed, rc e_m)
+        const double rc = (j == unit) ? (s.slot_var ? em : 0.0) : fma(em, rowr[j], s.T[s.m * s.ld + j]);
         if (s.pricing == LPX_PRICE_DANTZIG) {
-            if (vi_less(rc, s.col0 + j, mn, jn)) { mn = rc; jn = s.col0 + j; }
+            if (vi_less(rc, t_var(s, j), mn, jn)) { mn = rc; jn = t_var(s, j); }
         } else {
             mn = fmin(mn, rc);
-            if (rc < 0.0 && s.col0 + j < jn) jn = s.col0 + j;
+            if (rc < 0.0 && t_var(s, j) < jn) jn = t_var(s, j);
         }
     }
     if (s.pricing == LPX_PRICE_DANTZIG) {
@@ -584,8 +615,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_propose_next(lpx_tableau s, Par
     if (i > s.m) return;
     double v = 0.0;
     if (j != LPX_NOIDX) {
-        const int64_t jl = j - s.col0, r = s.ctrl->leave_r;
-        if (jl == t_unit_col(s)) v = (i == r) ? 1.0 : 0.0;
+        const int64_t jl = t_slot(s, j), r = s.ctrl->leave_r;
+        if (jl == t_unit_col(s)) v = s.slot_var ? e[i] : ((i == r) ? 1.0 : 0.0);
         else v = (i == r) ? e[i] * rowr[jl] : fma(e[i], rowr[jl], s.T[i * s.ld + jl]);
     }
     sendbuf[2 + i] = v;
@@ -802,6 +833,7 @@ extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, voi
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
     LPX_REQUIRE(s->col0 == 0 && s->n_global == s->n, "lpx_tableau_dual_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -826,6 +858,7 @@ extern "C" int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, v
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
     LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -842,6 +875,7 @@ extern "C" int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvb
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;

@@ -175,8 +175,10 @@ def main():
         assert res.basis.tolist() == want.basis.tolist() and res.optimum == (want.status == O.OPTIMAL)
         assert np.allclose(res.x, want.x, rtol=1e-9, atol=1e-9) and abs(res.cost - want.cost) <= 1e-9 * max(1, abs(want.cost))
         # slice-construction path used by bench.py (columns=...)
-        Ab, bb, cb, basb = problems.gen_primal_columns(m, n, seed, *column_range(n, rank, world))
-        s2 = cls(cb, Ab, bb, basb, group=dist.group.WORLD, columns=column_range(n, rank, world), n_global=n)
+        # (condensed form, the default: only nonbasic columns are carried -- with the slack basis the n - m structural ones)
+        ncarry = n - m if cls.CONDENSED else n
+        Ab, bb, cb, basb = problems.gen_primal_columns(m, n, seed, *column_range(ncarry, rank, world))
+        s2 = cls(cb, Ab, bb, basb, group=dist.group.WORLD, columns=column_range(ncarry, rank, world), n_global=n)
         r2 = s2.solve(maxiters)
         full = problems.gen_primal_columns(m, n, seed, 0, n)
         w2 = O.OracleTableau(full[2], full[0], full[1], full[3], log_cap=maxiters + 1).solve(maxiters)

@@ -40,12 +40,15 @@ def test_product_path_two_ranks_one_gpu(nproc, m, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"LPX_TABLEAU_SMALL": "0"}, {"LPX_TABLEAU_LOOKAHEAD": "0"},
-                                 {"LPX_TABLEAU_SMALL": "0", "LPX_TABLEAU_LOOKAHEAD": "0"}],
+                                 {"LPX_TABLEAU_SMALL": "0", "LPX_TABLEAU_LOOKAHEAD": "0"},
+                                 {"LPX_TABLEAU_CONDENSED": "0"}, {"LPX_TABLEAU_CONDENSED": "0", "LPX_TABLEAU_SMALL": "0"},
+                                 {"LPX_TABLEAU_CONDENSED": "0", "LPX_TABLEAU_LOOKAHEAD": "0"}],
                          ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
 def test_product_path_lookahead_and_kernel_variants(env):
     """The default run above overlaps the exchange of pivot t+1 with the update of pivot t (lpx_tableau_commit_begin /
     _update) behind the single-workgroup prologue; here the multi-workgroup select/prepare chain with lookahead, and both
-    chains with the plain propose -> all-gather -> commit loop.  All must give the oracle's pivot sequence."""
+    chains with the plain propose -> all-gather -> commit loop, and the full (every column) layout instead of the condensed
+    one.  All must give the oracle's pivot sequence."""
     _run("gpu", 2, 64, 128, 2, 100000, **env)
 
 

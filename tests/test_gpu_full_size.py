@@ -33,14 +33,26 @@ def test_config4_tableau_invariants():
     assert costs[0] >= costs[1] >= costs[2] and costs[2] < 0
     log = s.pivot_log()
     assert len(log) == K
-    T = s._engine.T
-    bas = torch.from_numpy(res.basis).cuda()
-    # basic columns are exact unit vectors, basic reduced costs exactly 0
-    cols = T[:, bas]                                   # (m+1) x m gather
-    assert bool((cols[:m].diagonal() == 1.0).all())
-    assert int((cols[:m] != 0).sum().item()) == m
-    assert bool((cols[m] == 0.0).all())
-    xB = T[:m, n].cpu().numpy()
+    eng = s._engine
+    T = eng.T
+    if eng.slot_var is None:
+        bas = torch.from_numpy(res.basis).cuda()
+        # basic columns are exact unit vectors, basic reduced costs exactly 0
+        cols = T[:, bas]                                   # (m+1) x m gather
+        assert bool((cols[:m].diagonal() == 1.0).all())
+        assert int((cols[:m] != 0).sum().item()) == m
+        assert bool((cols[m] == 0.0).all())
+    else:
+        # condensed form (default): only nonbasic columns are carried; slots and basis partition the variables, and a
+        # sample of carried columns equals B^-1 A_j recomputed in float64 on the host
+        slot_var, var_slot = eng.slot_var.cpu().numpy(), eng.var_slot.cpu().numpy()
+        assert eng.n == n - m and np.array_equal(np.sort(np.concatenate([slot_var, res.basis])), np.arange(n))
+        assert np.array_equal(var_slot[slot_var], np.arange(eng.n)) and np.all(var_slot[res.basis] == -1)
+        Bm = A[:, res.basis].astype(np.float64)
+        for k in (0, 777, eng.n - 1):
+            col = np.linalg.solve(Bm, A[:, slot_var[k]].astype(np.float64))
+            assert np.abs(T[:m, k].cpu().numpy() - col).max() < 1e-8
+    xB = T[:m, eng.n].cpu().numpy()
     assert xB.min() >= 0.0
     x = res.x
     assert np.array_equal(x[res.basis], xB) and np.count_nonzero(x) <= m

@@ -14,13 +14,16 @@ def logged(cls, cap):
     return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
 
 
+@pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
 @pytest.mark.parametrize("cs", PRIMAL, ids=case_id)
-def test_tableau_matches_reference(cs):
+def test_tableau_matches_reference(cs, condensed):
+    """Both layouts of the carried tableau -- nonbasic columns only (the default) and every column -- against the
+    reference's golden pivot sequences and results."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
 
     ref = cs["ref"]
     c, A, b, basis = problem_of(cs)
-    s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis)
+    s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis, condensed=condensed)
     res = s.solve(cs.get("maxiters", 100))
     assert s.pivot_log().tolist() == ref["pivots"]
     assert res.iters == ref["iters"] and res.optimum == ref["optimum"] and res.basis.tolist() == ref["basis"]
@@ -35,13 +38,22 @@ def test_tableau_bit_exact_vs_oracle():
     from oracle import oracle as O
 
     c, A, b, basis = gen.gen_primal(96, 200, 11)
-    s = PrimalTableauSimplexSolver(c, A, b, basis)
+    s = PrimalTableauSimplexSolver(c, A, b, basis, condensed=False)
+    sc = PrimalTableauSimplexSolver(c, A, b, basis, condensed=True)
     o = O.OracleTableau(c, A, b, basis)
     for k in (1, 7, 40):
         s.solve(k)
+        sc.solve(k)
         o.solve(k)
         T = s._engine.T.cpu().numpy()
         assert np.array_equal(T[:, :201], o.T[:, :201])
+        # condensed form: slot k carries variable slot_var[k]; the slots and the basis partition the variables
+        eng = sc._engine
+        Tc, slot_var, var_slot = eng.T.cpu().numpy(), eng.slot_var.cpu().numpy(), eng.var_slot.cpu().numpy()
+        assert eng.n == 200 - 96 and sorted(slot_var.tolist() + sc.basis.tolist()) == list(range(200))
+        assert np.array_equal(var_slot[slot_var], np.arange(eng.n)) and np.all(var_slot[sc.basis] == -1)
+        assert np.array_equal(Tc[:, :eng.n], o.T[:, slot_var])
+        assert np.array_equal(Tc[:, eng.n], o.T[:, 200])
 
 
 def test_tableau_unbounded_and_infeasible_start():
