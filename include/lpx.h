@@ -77,7 +77,8 @@ typedef struct lpx_ctrl {
     double aux_val;       /* max(d) (primal), min(row) (dual) */
     int32_t flip;         /* bounded: 1 if the last iteration was a bound flip (no basis change) */
     int32_t leave_state;  /* bounded: LPX_VS_LOWER / LPX_VS_UPPER the leaving variable went to */
-    int64_t reserved[6];
+    int64_t enter_slot;   /* tableau form: local column of T that the update of the last pivot rewrites as a whole, or -1 */
+    int64_t reserved[5];
 } lpx_ctrl;
 
 /* State of one LP in revised form (explicit B^-1, primal_solvers.py:13-41).  A host-side struct of DEVICE

@@ -28,7 +28,7 @@ class LpxCtrl(C.Structure):
         ("counter", i64), ("pivots", i64), ("enter_j", i64), ("leave_r", i64), ("leave_var", i64),
         ("price_val", C.c_double), ("ratio_val", C.c_double), ("aux_val", C.c_double),
         ("flip", C.c_int32), ("leave_state", C.c_int32),
-        ("reserved", i64 * 6),
+        ("enter_slot", i64), ("reserved", i64 * 5),
     ]
 
 

@@ -60,12 +60,10 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
         if (TABLEAU) {
             // local index of the entering column; another rank's column (column partition) must not alias the
             // x_B column at local index cols-1
-            if (a.var_slot) {
-                unit_col = a.var_slot[a.ctrl->leave_var]; // k_t_prepare has handed the slot over already
-            } else {
-                unit_col = a.ctrl->enter_j - a.col0;
-                if (unit_col < 0 || unit_col >= a.cols - 1) unit_col = -1;
-            }
+            // local column rewritten as a whole (unit vector / eta column), left by the prepare kernel; another rank's
+            // column (column partition) gives -1 and cannot alias the x_B column at local index cols-1
+            unit_col = a.ctrl->enter_slot;
+            if (unit_col < 0 || unit_col >= a.cols - 1) unit_col = -1;
         }
     }
     const int nthr = blockDim.x;

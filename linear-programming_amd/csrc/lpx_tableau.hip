@@ -83,6 +83,10 @@ __device__ __forceinline__ int64_t t_slot(const lpx_tableau &s, int64_t j)
     return (k < 0 || k >= s.n) ? -1 : k;
 }
 // bookkeeping of a basis change (single thread): the full form flips var_state, the condensed form hands the slot over
+// It leaves ctrl->enter_slot = the local column that the update rewrites as a whole (full form: the entering variable's,
+// which becomes a unit vector; condensed: the slot handed to the leaving variable, which receives the eta column), -1 if
+// that column is not on this rank.  K1 reads it with the rest of the control block (no lookup through var_slot in
+// front of its 10^5..10^6 short workgroups).
 __device__ __forceinline__ void t_swap_columns(const lpx_tableau &s, int64_t j, int64_t leaving)
 {
     if (s.slot_var) {
@@ -92,18 +96,15 @@ __device__ __forceinline__ void t_swap_columns(const lpx_tableau &s, int64_t j, 
             s.var_slot[leaving] = k;
         }
         s.var_slot[j] = -1;
+        s.ctrl->enter_slot = k;
         return;
     }
     const int64_t ll = leaving - s.col0, jl = j - s.col0;
     if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
     if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+    s.ctrl->enter_slot = (jl >= 0 && jl < s.n) ? jl : -1;
 }
-// after the bookkeeping of this pivot: the local column that the update rewrites as a whole (full form: the entering
-// variable's, which becomes a unit vector; condensed: the slot that now belongs to the leaving variable), -1 if none here
-__device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s)
-{
-    return t_slot(s, s.slot_var ? s.ctrl->leave_var : s.ctrl->enter_j);
-}
+__device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s) { return s.ctrl->enter_slot; }
 
 // K3 (tableau): scan the carried reduced-cost row: one partial (min rc, first global column with rc<0) per
 // column strip of K1's launch plan, i.e. in the same layout K1's fused pricing epilogue writes afterwards.
@@ -739,9 +740,7 @@ __device__ __forceinline__ void td_finish(const lpx_tableau &s, int64_t r, int64
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t leaving = s.basis[r];
         s.basis[r] = j;
-        const int64_t ll = leaving - s.col0, jl = j - s.col0;
-        if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
-        if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
+        t_swap_columns(s, j, leaving);
         if (s.log && ctrl->pivots < s.log_cap) {
             s.log[3 * ctrl->pivots + 0] = r;
             s.log[3 * ctrl->pivots + 1] = j;
