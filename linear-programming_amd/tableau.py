@@ -130,10 +130,12 @@ class TableauEngine:
     # ------------------------------------------------------------------ construction from a host problem
     @classmethod
     def from_columns(cls, A_cols32, b32, c32_global, basis, col0, n_global, inv32=None, bfs32=None, ld_align=None,
-                     var_ids=None, condensed=False, **kw):
+                     var_ids=None, condensed=False, start32=None, **kw):
         """Build the local slice from columns of the float32 A (slack basis unless inv32): columns [col0, col0+n_local),
         or the variables ``var_ids``.  ``condensed``: carry only the nonbasic ones of them (the basic columns of a
-        tableau are unit vectors that no pivot changes)."""
+        tableau are unit vectors that no pivot changes).  ``start32`` = (inv32 @ A, c - c_B @ inv32 @ A) for ALL columns,
+        formed by the caller on the host with the reference's float32 NumPy expressions (the device's float32 matmul
+        rounds differently)."""
         torch = torch_cuda()
         basis_np = np.asarray(basis, dtype=np.int64)
         if var_ids is None:
@@ -165,11 +167,16 @@ class TableauEngine:
             T[m, :n_local].copy_(rc)
             T[m, n_local] = -float(cb.astype(np.float64) @ np.asarray(b32, dtype=np.float64))
         else:  # the reference's float32 starting state (primal_solvers.py:37-38, :64), carried as a tableau
-            inv_dev = to_device(np.asarray(inv32, dtype=np.float32))
-            T[:m, :n_local].copy_(inv_dev @ A_dev)
+            if start32 is not None:
+                BA32, rc32 = start32
+                T[:m, :n_local].copy_(to_device(np.ascontiguousarray(BA32[:, var_ids])))
+                T[m, :n_local].copy_(to_device(np.ascontiguousarray(rc32[var_ids])))
+            else:
+                inv_dev = to_device(np.asarray(inv32, dtype=np.float32))
+                T[:m, :n_local].copy_(inv_dev @ A_dev)
+                y32 = to_device(cb.astype(np.float32)) @ inv_dev
+                T[m, :n_local].copy_(c_dev[ids_dev] - y32 @ A_dev)
             T[:m, n_local].copy_(to_device(np.asarray(bfs32, dtype=np.float64)))
-            y32 = to_device(cb.astype(np.float32)) @ inv_dev
-            T[m, :n_local].copy_(c_dev[ids_dev] - y32 @ A_dev)
             T[m, n_local] = -float(cb @ np.asarray(bfs32, dtype=np.float32))
         del A_dev
         if condensed:
@@ -303,7 +310,7 @@ class PrimalTableauSimplexSolver:
             self.m, self.n = A_cols.shape[0], int(n_global)
             A32 = None
         self.basis = np.array(basis).astype(int)
-        inv32 = bfs32 = None
+        inv32 = bfs32 = start32 = None
         k = self.n - self.m
         slack = np.array_equal(self.basis, np.arange(k, self.n)) and (
             self._slack_block_is_identity(A_cols, j0, j1, k) if A32 is None else self._slack_block_is_identity(A32, 0, self.n, k))
@@ -312,13 +319,14 @@ class PrimalTableauSimplexSolver:
                 raise ValueError("a non-slack starting basis needs the whole matrix")
             inv32 = np.linalg.inv(A32[:, self.basis])  # primal_solvers.py:37
             bfs32 = inv32 @ self.b
+            start32 = (inv32 @ A32, self.c - self.c[self.basis] @ inv32 @ A32)  # :64, float32 like the reference's
         if not np.all((self.b if bfs32 is None else bfs32) >= 0.0):  # primal_solvers.py:43-48
             raise BasisIsPrimalInfeasibleError
         self.counter = None
         self.optimum = None
         self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
                                                   bfs32=bfs32, log_cap=self._LOG_CAP, group=group, pricing=pricing,
-                                                  var_ids=var_ids, condensed=condensed)
+                                                  var_ids=var_ids, condensed=condensed, start32=start32)
 
     @staticmethod
     def _slack_block_is_identity(A_cols, j0, j1, k):
@@ -366,8 +374,10 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
             j0, j1 = column_range(self.n, dist.get_rank(group), dist.get_world_size(group))
         self.counter = None
         self.optimum = None
+        start32 = (inv32 @ A32, self.c - self.c[self.basis] @ inv32 @ A32)
         self._engine = TableauEngine.from_columns(A32[:, j0:j1], self.b, self.c, self.basis, j0, self.n, inv32=inv32,
-                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group, dual=True)
+                                                  bfs32=bfs32, log_cap=self._LOG_CAP, group=group, dual=True,
+                                                  start32=start32)
 
     def solve(self, maxiters: int = 100):
         self.counter = 0

@@ -174,7 +174,22 @@ def main():
         assert s.pivot_log().tolist() == want.log.tolist(), f"rank {rank}: pivot sequence differs"
         assert res.basis.tolist() == want.basis.tolist() and res.optimum == (want.status == O.OPTIMAL)
         assert np.allclose(res.x, want.x, rtol=1e-9, atol=1e-9) and abs(res.cost - want.cost) <= 1e-9 * max(1, abs(want.cost))
-        # slice-construction path used by bench.py (columns=...)
+        # a non-slack starting basis (float32 inverse start, primal_solvers.py:37-38): the nonbasic variables are then a
+        # mix of structural and slack columns, partitioned by position in the sorted nonbasic list
+        mid = O.OracleRevised(c, A, b, basis, log_cap=16).solve(9).basis.copy()
+        # From a float32-inverted start the carried basic columns of the FULL layout are inv32 @ A[:, basis], an identity
+        # only to float32 accuracy, and its pivots follow the oracle's tableau loop; the condensed layout carries no basic
+        # columns -- they are exact unit vectors by construction, as in the reference, which re-derives everything from
+        # B^-1 -- and follows the reference's (revised) sequence.  x agrees with the other form to float32 accuracy.
+        Same, Other = (O.OracleRevised, O.OracleTableau) if cls.CONDENSED else (O.OracleTableau, O.OracleRevised)
+        w3 = Same(c, A, b, mid, log_cap=maxiters + 1).solve(maxiters)
+        s3 = cls(c, A, b, mid, group=dist.group.WORLD)
+        r3 = s3.solve(maxiters)
+        assert s3.pivot_log().tolist() == w3.log.tolist(), f"rank {rank}: pivot sequence differs (non-slack start)"
+        assert r3.optimum == (w3.status == O.OPTIMAL) and r3.basis.tolist() == w3.basis.tolist()
+        assert np.allclose(r3.x, w3.x, rtol=1e-5, atol=1e-5)
+        w4 = Other(c, A, b, mid, log_cap=4).solve(maxiters)
+        assert abs(r3.cost - w4.cost) <= 1e-5 * max(1.0, abs(w4.cost))
         # (condensed form, the default: only nonbasic columns are carried -- with the slack basis the n - m structural ones)
         ncarry = n - m if cls.CONDENSED else n
         Ab, bb, cb, basb = problems.gen_primal_columns(m, n, seed, *column_range(ncarry, rank, world))
