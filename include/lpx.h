@@ -124,7 +124,7 @@ typedef struct lpx_tableau {
     int64_t log_cap;
     void *workspace;
     int64_t workspace_bytes;
-    /* Condensed form (both non-NULL; primal entry points only): T holds the NONBASIC columns only -- basic columns are
+    /* Condensed form (both non-NULL): T holds the NONBASIC columns only -- basic columns are
      * unit vectors that no pivot changes -- so n counts column slots, slot_var[k] is the variable in slot k and
      * var_slot[j] (n_global entries) the slot of variable j on this rank or -1.  col0 is unused.  Same arithmetic, about
      * half the memory and HBM traffic per pivot at n = 2m.  Both NULL: every column is carried (full form). */

@@ -711,9 +711,10 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_ratio(lpx_tableau s, Partials 
     VI best{LPX_INF, LPX_NOIDX};
     double rowmin = LPX_INF;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
-        const double row = (s.var_state[j] == LPX_VS_BASIC) ? 0.0 : s.T[r * s.ld + j];
+        // basic columns count as 0 (dual_solvers.py:38-39); the condensed form carries none
+        const double row = (!s.slot_var && s.var_state[j] == LPX_VS_BASIC) ? 0.0 : s.T[r * s.ld + j];
         const double th = lpx_dsd(s.T[s.m * s.ld + j], row, f32);
-        if (vi_less(th, s.col0 + j, best.v, best.i)) { best.v = th; best.i = s.col0 + j; }
+        if (vi_less(th, t_var(s, j), best.v, best.i)) { best.v = th; best.i = t_var(s, j); }
         rowmin = fmin(rowmin, row);
     }
     best = block_argmin(best, red);
@@ -773,9 +774,10 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_prepare(lpx_tableau s, Partial
         return;
     }
     const int64_t r = ctrl->leave_r, j = t.i; // leave_r: written by k_td_ratio, only read here
-    const double dr = s.T[r * s.ld + (j - s.col0)];
+    const int64_t jl = t_slot(s, j);
+    const double dr = s.T[r * s.ld + jl];
     const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    const double di = (gi <= s.m) ? s.T[gi * s.ld + (j - s.col0)] : 0.0;
+    const double di = (gi <= s.m) ? s.T[gi * s.ld + jl] : 0.0;
     td_finish(s, r, j, dr, di, t.v, rowmin, d, e, rowr);
 }
 
@@ -790,11 +792,11 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_propose(lpx_tableau s, Partial
         sendbuf[1] = (double)t.i;
     }
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
-    if (i <= s.m) sendbuf[2 + i] = s.T[i * s.ld + (t.i - s.col0)];
+    if (i <= s.m) sendbuf[2 + i] = s.T[i * s.ld + t_slot(s, t.i)];
 }
 
-// column-partitioned, part 2: global entering column = first argmin of theta over the ranks' proposals (ranks own
-// ascending column ranges, so "lowest global index on ties" is np.argmin's first minimum).  No candidate anywhere
+// column-partitioned, part 2: global entering column = first argmin of theta over the ranks' proposals ("lowest variable
+// index on ties" is np.argmin's first minimum, whichever rank holds the variable).  No candidate anywhere
 // (every theta = +inf) is exactly min(row) >= 0: dual unbounded.
 __global__ __launch_bounds__(LPX_BLOCK) void k_td_commit(lpx_tableau s, const double *recv, int64_t nranks, int64_t msg, double *d,
                                                         double *e, double *rowr)
@@ -832,8 +834,7 @@ extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, voi
 {
     int rc = check_tableau(s);
     if (rc) return rc;
-    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
-    LPX_REQUIRE(s->col0 == 0 && s->n_global == s->n, "lpx_tableau_dual_iterate needs an unpartitioned tableau");
+    LPX_REQUIRE(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n), "lpx_tableau_dual_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
@@ -857,7 +858,6 @@ extern "C" int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, v
 {
     int rc = check_tableau(s);
     if (rc) return rc;
-    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
     LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -874,7 +874,6 @@ extern "C" int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvb
 {
     int rc = check_tableau(s);
     if (rc) return rc;
-    LPX_REQUIRE(s->slot_var == nullptr, "the dual loop works on the full form (slot_var = var_slot = NULL)");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;

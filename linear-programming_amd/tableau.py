@@ -90,7 +90,7 @@ class TableauEngine:
         torch = torch_cuda()
         self.dual = bool(dual)
         self.slot_var, self.var_slot = slot_var, var_slot  # condensed form: nonbasic columns only (lpx.h)
-        assert (slot_var is None) == (var_slot is None) and not (dual and slot_var is not None)
+        assert (slot_var is None) == (var_slot is None)
         self.torch = torch
         self.lib = _lib.load()
         self.m, self.n = int(m), int(n_local)
@@ -359,7 +359,8 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
     ``DualIsUnboundedError`` (:41-44).  ``optimum`` stays ``None`` until optimality is reached, as in the reference.
     ``group`` column-partitions the tableau exactly as for the primal solver."""
 
-    def __init__(self, c, A, b, basis, group=None):
+    def __init__(self, c, A, b, basis, group=None, condensed=None):
+        condensed = self.CONDENSED if condensed is None else bool(condensed)
         self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
         self.m, self.n = A32.shape
         self.basis = np.array(basis).astype(int)
@@ -367,17 +368,24 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
         bfs32 = inv32 @ self.b
         if not np.all(self.c[self.basis] @ inv32 @ A32 <= self.c):  # dual_solvers.py:14-16
             raise BasisIsDualInfeasibleError
-        j0, j1 = 0, self.n
+        j0, j1, var_ids = 0, self.n, None
         if group is not None:
             import torch.distributed as dist
 
-            j0, j1 = column_range(self.n, dist.get_rank(group), dist.get_world_size(group))
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            if condensed:
+                nonbasic = np.setdiff1d(np.arange(self.n), self.basis)
+                lo, hi = column_range(nonbasic.size, rank, world)
+                var_ids = nonbasic[lo:hi]
+            else:
+                j0, j1 = column_range(self.n, rank, world)
         self.counter = None
         self.optimum = None
         start32 = (inv32 @ A32, self.c - self.c[self.basis] @ inv32 @ A32)
-        self._engine = TableauEngine.from_columns(A32[:, j0:j1], self.b, self.c, self.basis, j0, self.n, inv32=inv32,
+        A_cols = A32[:, j0:j1] if var_ids is None else A32[:, var_ids]
+        self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
                                                   bfs32=bfs32, log_cap=self._LOG_CAP, group=group, dual=True,
-                                                  start32=start32)
+                                                  start32=start32, var_ids=var_ids, condensed=condensed)
 
     def solve(self, maxiters: int = 100):
         self.counter = 0
