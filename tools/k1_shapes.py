@@ -12,9 +12,10 @@ from linprog_amd import _lib  # noqa: E402
 
 L = _lib.load()
 REP = 10
-for rows, cols in [(20001, 40001), (20001, 20001), (20001, 19968), (20001, 20480), (20001, 20225), (40001, 20001),
-                   (20001, 10001), (20001, 5001)]:
-    ld = -(-cols // 512) * 512
+SHAPES = [(20001, 40001, 0), (20001, 20001, 0), (20001, 19968, 0), (20001, 20480, 0), (40001, 20001, 0), (20001, 10001, 0),
+          (20001, 5001, 0), (20001, 2501, 0), (20001, 2501, 512), (20001, 2501, 1536), (20001, 40001, 512), (20001, 20001, 1024)]
+for rows, cols, extra in SHAPES:  # extra: additional row padding (doubles) on top of the 4-KiB alignment
+    ld = -(-cols // 512) * 512 + extra
     M = torch.rand((rows, ld), dtype=torch.float64, device="cuda")
     e = (torch.rand(rows, dtype=torch.float64, device="cuda") - 0.5) * 1e-3
     scr = torch.zeros(ld + 2, dtype=torch.float64, device="cuda")
