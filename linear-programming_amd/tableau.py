@@ -289,10 +289,14 @@ class PrimalTableauSimplexSolver:
             self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
             self.m, self.n = A32.shape
             j0, j1 = 0, self.n
+            world = 1
             if group is not None:
                 import torch.distributed as dist
 
                 rank, world = dist.get_rank(group), dist.get_world_size(group)
+            # fewer nonbasic columns than ranks (n = m: none at all): every rank falls back to the full layout
+            condensed = condensed and self.n - len(set(np.asarray(basis, dtype=np.int64).tolist())) >= world
+            if group is not None:
                 if condensed:  # partition the nonbasic variables, not the column range: a slack basis is a whole range
                     nonbasic = np.setdiff1d(np.arange(self.n), np.asarray(basis, dtype=np.int64))
                     lo, hi = column_range(nonbasic.size, rank, world)
@@ -369,10 +373,13 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
         if not np.all(self.c[self.basis] @ inv32 @ A32 <= self.c):  # dual_solvers.py:14-16
             raise BasisIsDualInfeasibleError
         j0, j1, var_ids = 0, self.n, None
+        rank, world = 0, 1
         if group is not None:
             import torch.distributed as dist
 
             rank, world = dist.get_rank(group), dist.get_world_size(group)
+        condensed = condensed and self.n - len(set(self.basis.tolist())) >= world  # else: full layout on every rank
+        if group is not None:
             if condensed:
                 nonbasic = np.setdiff1d(np.arange(self.n), self.basis)
                 lo, hi = column_range(nonbasic.size, rank, world)

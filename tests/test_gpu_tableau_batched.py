@@ -326,3 +326,19 @@ def test_batched_dual_reference_sequences_limits_and_errors():
     c, A, b, basis = gen.gen_primal(8, 16, 0)  # not dual feasible at the slack basis
     with pytest.raises(exceptions.BasisIsDualInfeasibleError):
         BatchedDualSolver(c[None], A[None], b[None], basis[None])
+
+
+def test_tableau_without_nonbasic_columns_falls_back_to_the_full_layout():
+    """n = m: every column is basic, nothing to condense; the solver answers 'optimal' at once like the reference."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    rng = np.random.default_rng(3)
+    A = np.eye(6) + 0.1 * rng.random((6, 6))
+    b = A @ rng.uniform(1, 2, 6)
+    c = rng.uniform(-1, 1, 6)
+    basis = np.arange(6)
+    t = PrimalTableauSimplexSolver(c, A, b, basis).solve()
+    r = PrimalRevisedSimplexSolver(c, A, b, basis).solve()
+    assert t.optimum and r.optimum and t.iters == r.iters == 1
+    assert np.allclose(t.x, r.x, rtol=1e-5, atol=1e-5)
