@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "config5"])
+    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "dual10k", "config5"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -99,6 +99,8 @@ def main():
         return bench_revised(args)
     if args.workload == "config5":
         return bench_config5(args)
+    if args.workload == "dual10k":
+        return bench_dual(args)
 
     m, n = (20000, 40000) if args.workload == "tableau" else (1000, 2000)
     K, W = args.steps, args.warmup
@@ -298,6 +300,85 @@ def bench_revised(args):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 16.0 * m * m / k1_s / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "avg_launch_ms": k1_s * 1e3,
                         "whole_iteration_GBs": iter_bytes * K / dt / 1e9},
+           "cpu_baseline": cpu}
+    emit(out)
+
+
+def bench_dual(args):
+    """The dual simplex (dual_solvers.py:82-108) at 10000 x 20000 from gen_dual's dual-feasible slack basis, in both forms:
+    the carried (condensed) tableau and the revised form.  Value = the tableau form's pivots/s."""
+    import ctypes as C
+
+    import torch
+
+    from linprog_amd import _lib, problems
+    from linprog_amd.dual_solvers import DualRevisedSimplexSolver
+    from linprog_amd.tableau import DualTableauSimplexSolver
+    from oracle import oracle as O
+
+    m, n = 10000, 20000
+    K, W = args.steps, args.warmup
+    c, A, b, basis = problems.gen_dual(m, n, args.seed)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(solver, enqueue):
+        eng = solver._engine
+        _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, st))
+        enqueue(eng, W)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enqueue(eng, K)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _lib.check(lib.lpx_profile_k1(1))
+        enqueue(eng, min(K, 100))
+        torch.cuda.synchronize()
+        k1_ms, k1_n = C.c_double(), C.c_int64()
+        _lib.check(lib.lpx_profile_k1_read(C.byref(k1_ms), C.byref(k1_n)))
+        _lib.check(lib.lpx_profile_k1(0))
+        ctrl = eng.read_ctrl()
+        if ctrl.pivots != W + K + min(K, 100) or ctrl.status != _lib.RUNNING:
+            sys.exit(f"bench invalid: {ctrl.pivots} pivots, status {ctrl.status}")
+        return dt, k1_ms.value / 1e3 / max(1, k1_n.value)
+
+    Tab = type("BenchDualTableau", (DualTableauSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
+    tab = Tab(c, A, b, basis)
+    dt_t, k1_t = run(tab, lambda eng, k: eng.enqueue(k))
+    log_t = tab.pivot_log()
+    ncarry = tab._engine.n
+    del tab
+    torch.cuda.empty_cache()
+    Rev = type("BenchDualRevised", (DualRevisedSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
+    rev = Rev(c, A, b, basis)
+    dt_r, k1_r = run(rev, lambda eng, k: eng.enqueue(_lib.KIND_DUAL, k))
+    log_r = rev.pivot_log()
+    same = min(len(log_t), len(log_r))
+    if log_t[:same].tolist() != log_r[:same].tolist():
+        sys.exit("bench invalid: the tableau and the revised form took different dual pivots")
+    kc = args.cpu_pivots if args.cpu_pivots is not None else 6
+    cpu = None
+    if kc > 0:
+        o = O.OracleRevised(c, A, b, basis, kind="dual", log_cap=kc + 1)
+        t1 = time.perf_counter()
+        r = o.solve(kc)
+        dc = time.perf_counter() - t1
+        if r.log.tolist() != log_t[:kc].tolist():
+            sys.exit("bench invalid: GPU dual pivot sequence differs from the oracle's")
+        cpu = {"value": kc / dc, "unit": "pivots/s", "cores": 1, "kind": "port",
+               "sample": f"first {kc} pivots, oracle dual revised loop (C, single thread)",
+               "parity": f"tableau form, revised form and oracle: sequences identical on these {kc} pivots; the two GPU "
+                         f"forms on all {same}"}
+    bytes_t = 16.0 * (m + 1) * (ncarry + 1)
+    out = {"metric": f"dual simplex pivots/sec ({m}x{n})", "value": K / dt_t, "unit": "pivots/s", "n_gpus": 1, "steps": K,
+           "warmup": W, "ms_per_step": dt_t / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"gen_dual(m={m}, n={n}, seed={args.seed}) DualTableauSimplexSolver loop (condensed tableau, "
+                                  f"{m + 1} x {ncarry + 1})", "m": m, "n": n,
+                      "revised_form_pivots_per_s": K / dt_r, "revised_form_k1_ms": k1_r * 1e3},
+           "roofline": {"bound": "hbm", "kernel": "k_rank1<tableau>", "achieved": bytes_t / k1_t / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": bytes_t / k1_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_launch": bytes_t, "avg_launch_ms": k1_t * 1e3},
            "cpu_baseline": cpu}
     emit(out)
 

@@ -15,17 +15,28 @@ from .exceptions import BasisIsPrimalInfeasibleError, PrimalIsUnboundedError
 from .preprocessing import ProblemPreprocessingUtils
 
 
+def signed_identity_diagonal(B):
+    """The diagonal of B if B is a diagonal matrix of +1 / -1 entries (a slack basis, possibly with rows flipped by
+    preprocessing.py:6-15), else None."""
+    m = B.shape[0]
+    d = B[np.arange(m), np.arange(m)]
+    if np.count_nonzero(B) == m and np.all(np.abs(d) == 1.0):
+        return d.astype(np.float32)
+    return None
+
+
 def _initial_inverse(A32, basis, b32):
     """inv_basis_matrix and bfs of the constructor (primal_solvers.py:37-38), float32.
 
-    A starting basis whose columns are the identity (the slack basis of every synthetic config) is recognised
-    without LAPACK: ``np.linalg.inv(I)`` is ``I`` exactly, so the result is the same and a 20k x 20k float32
-    inversion on the host is avoided.
+    A starting basis whose columns are the identity up to sign (the slack basis of every synthetic config; minus signs
+    where preprocessing flipped a row) is recognised without LAPACK: ``np.linalg.inv`` of such a matrix is the matrix
+    itself, exactly, so the result is the same and a 20k x 20k float32 inversion on the host is avoided.
     """
     m = A32.shape[0]
     B = A32[:, basis]
-    if np.count_nonzero(B) == m and np.all(B[np.arange(m), np.arange(m)] == 1.0):
-        return np.eye(m, dtype=np.float32), b32.copy()
+    d = signed_identity_diagonal(B)
+    if d is not None:
+        return np.diag(d), d * b32
     inv32 = np.linalg.inv(B)
     return inv32, inv32 @ b32
 

@@ -19,6 +19,7 @@ from .device import roundup, stream_ptr, to_device, torch_cuda
 from .exceptions import (BasisIsDualInfeasibleError, BasisIsPrimalInfeasibleError, DualIsUnboundedError,
                          PrimalIsUnboundedError)
 from .preprocessing import ProblemPreprocessingUtils
+from .primal_solvers import signed_identity_diagonal
 
 
 def row_alignment(cols):
@@ -368,9 +369,16 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
         self.c, A32, self.b = ProblemPreprocessingUtils.preprocess_problem(c, A, b)
         self.m, self.n = A32.shape
         self.basis = np.array(basis).astype(int)
-        inv32 = np.linalg.inv(A32[:, self.basis])  # primal_solvers.py:37
-        bfs32 = inv32 @ self.b
-        if not np.all(self.c[self.basis] @ inv32 @ A32 <= self.c):  # dual_solvers.py:14-16
+        d = signed_identity_diagonal(A32[:, self.basis])
+        if d is not None:  # +-identity basis: its inverse is itself and inv32 @ A is a row scaling, both exact
+            inv32, bfs32 = np.diag(d), d * self.b
+            BA32, z32 = A32 * d[:, None], (self.c[self.basis] * d) @ A32
+        else:
+            inv32 = np.linalg.inv(A32[:, self.basis])  # primal_solvers.py:37
+            bfs32 = inv32 @ self.b
+            BA32, z32 = inv32 @ A32, self.c[self.basis] @ inv32 @ A32
+        start32 = (BA32, self.c - z32)
+        if not np.all(z32 <= self.c):  # dual_solvers.py:14-16
             raise BasisIsDualInfeasibleError
         j0, j1, var_ids = 0, self.n, None
         rank, world = 0, 1
@@ -388,7 +396,6 @@ class DualTableauSimplexSolver(PrimalTableauSimplexSolver):
                 j0, j1 = column_range(self.n, rank, world)
         self.counter = None
         self.optimum = None
-        start32 = (inv32 @ A32, self.c - self.c[self.basis] @ inv32 @ A32)
         A_cols = A32[:, j0:j1] if var_ids is None else A32[:, var_ids]
         self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
                                                   bfs32=bfs32, log_cap=self._LOG_CAP, group=group, dual=True,
