@@ -283,6 +283,14 @@ int lpx_batched_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, 
 int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
                                   int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                                   int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
+/* The same solver semantics per LP with the CONDENSED TABLEAU as carried state (nonbasic columns of B^-1 A, reduced-cost
+ * row, x_B; lpx_tableau's layout) instead of B^-1: one rank-1 update per pivot, the tableau in registers, one wave per LP.
+ * Arithmetic of the tableau loop (bit-identical to the oracle's lpo_tableau_solve), the reference's pivot sequences.
+ * m <= 64, n - m <= 64; the starting basis is the slack block: columns n-m .. n-1 are the identity, their costs are 0,
+ * b >= 0 (caller's check; no Binv0).  basis is output only. */
+int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                              int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
+                              int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
 
 /* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
 /* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:

@@ -126,6 +126,29 @@ class BatchedDualSolver(BatchedPrimalSolver):
         return True if status == _lib.OPTIMAL else None
 
 
+class BatchedTableauSolver(BatchedPrimalSolver):
+    """The same per-LP semantics with the condensed tableau as carried state (``lpx_batched_tableau_solve``): one rank-1
+    update per pivot instead of three chains of m dependent fmas, the tableau in registers.  Bit-identical to the oracle's
+    tableau loop; the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64, slack starting basis
+    with zero basic costs (what ``from_inequalities`` and every synthetic config start from)."""
+
+    def __init__(self, c, A, b, basis, log_cap=0):
+        super().__init__(c, A, b, basis, log_cap=log_cap)
+        k = self.n - self.m
+        c32 = np.asarray(c).astype(np.float32)
+        if (self.Binv0 is not None or not np.array_equal(np.asarray(basis), np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
+                or np.any(c32[:, k:] != 0)):
+            raise ValueError("BatchedTableauSolver starts from the slack basis (identity columns n-m..n-1, zero costs)")
+        if self.m > 64 or k > 64:
+            raise ValueError("BatchedTableauSolver: m <= 64 and n - m <= 64")
+
+    def enqueue(self, maxiters):
+        _lib.check(self.lib.lpx_batched_tableau_solve(
+            self.B, self.m, self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),
+            self.x.data_ptr(), self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(), self.pivots.data_ptr(),
+            int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
+
+
 def solve_many(problems, maxiters=100):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
     launches of different shapes run on separate streams, results come back in input order."""

@@ -1,0 +1,159 @@
+// lpx_batched_tab.hip -- batches of small LPs in CONDENSED TABLEAU form, one wave per LP, the tableau in registers.
+//
+// Same rules as lpx_batched_primal_solve (primal_solvers.py:135-167 per LP), different carried state: instead of B^-1
+// (three chains of m dependent fmas per pivot: y, rc, d, plus the update) the wave carries the nonbasic columns of
+// T = B^-1 A, the reduced-cost row and x_B -- lpx_tableau's condensed layout -- and a pivot is ONE rank-1 update with one
+// fma per element.  Lane t owns column slot t: its m entries and its reduced cost live in registers for the whole solve
+// (130 VGPRs at m = 64); lane t also owns x_B[t] and basis[t].  Per pivot: two ballots price the row (any rc < 0?  any
+// rc < -1e-8?), a wave min over variable ids gives the first negative index, the entering lane publishes its column
+// through LDS, lane t forms its ratio and its eta entry e_t, and every lane updates its own column with the e_i read
+// back from LDS.  No dependent chains, ~1 KB of LDS per LP (so occupancy is set by registers, not LDS).
+// Arithmetic = the tableau loop's (lpx_tableau.hip, lpo_tableau_solve): bit-identical to that oracle, the reference's pivot
+// sequences.  Starting basis: the slack block (identity columns n-m .. n-1) with zero basic costs, checked by the caller.
+#include "lpx_device.hpp"
+
+#define TB_MAX 64
+// one case per row: r is wave-uniform, so "register r of this lane" is a scalar branch, not 64 selects
+#define TB_ROWS8(F, b) F(b + 0) F(b + 1) F(b + 2) F(b + 3) F(b + 4) F(b + 5) F(b + 6) F(b + 7)
+#define TB_ROWS(F) TB_ROWS8(F, 0) TB_ROWS8(F, 8) TB_ROWS8(F, 16) TB_ROWS8(F, 24) TB_ROWS8(F, 32) TB_ROWS8(F, 40) TB_ROWS8(F, 48) TB_ROWS8(F, 56)
+
+// value of v in lane `lane` (wave-uniform, compile-time or scalar) as a scalar: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double tb_readlane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+struct TabBatchArgs {
+    int64_t batch, m, n;
+    const float *A, *b, *c;
+    int64_t *basis;
+    double *x, *cost;
+    int32_t *status;
+    int64_t *iters, *pivots;
+    int64_t maxiters;
+    int64_t *log;
+    int64_t log_cap;
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batched_tab(TabBatchArgs a)
+{
+    __shared__ double dcol[TB_MAX + 2];
+    __shared__ double xs[2 * TB_MAX];
+    __shared__ float cf[2 * TB_MAX];
+    const int t = threadIdx.x;
+    const int64_t lp = blockIdx.x;
+    const int m = (int)a.m, n = (int)a.n, k = n - m;
+    const bool col = t < k, row = t < m;
+    const float *A = a.A + lp * a.m * a.n;
+
+    double x[TB_MAX];
+#pragma unroll
+    for (int i = 0; i < TB_MAX; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * n + t] : 0.0;
+    double rc = col ? (double)a.c[lp * n + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+    double xb = row ? (double)a.b[lp * m + t] : 0.0;
+    int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
+    int64_t bas = row ? (int64_t)(k + t) : -1;  // basis[t]
+    for (int j = t; j < n; j += 64) cf[j] = a.c[lp * n + j];
+
+    bool f32 = true; // the first ratio test divides in float32
+    int32_t status = LPX_RUNNING;
+    int64_t counter = 0, pivots = 0;
+    while (counter < a.maxiters) {
+        counter += 1;
+        const bool neg = col && rc < 0.0;
+        // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (primal_solvers.py:140-142) <=> no rc below -1e-8
+        if (__ballot(neg) == 0 || __ballot(col && rc < -LPX_ATOL) == 0) {
+            status = LPX_OPTIMAL;
+            break;
+        }
+        const int64_t jv = wave_imin(neg ? var : LPX_NOIDX); // first negative index, by variable id (:135-138)
+        const int jl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(var == jv)) - 1);
+        // the entering column goes from registers of one lane to one entry per lane: through LDS
+        if (t == jl) {
+#pragma unroll
+            for (int i = 0; i < TB_MAX; ++i) dcol[i] = x[i];
+        }
+        const double rcj = tb_readlane(rc, jl);
+        __syncthreads();
+        const double d = row ? dcol[t] : 0.0;
+        if (__ballot(row && d > 0.0) == 0) { // max(d) <= 0 (:144-147)
+            status = LPX_PRIMAL_UNBOUNDED;
+            break;
+        }
+        VI th{row ? lpx_psd(xb, d, f32) : LPX_INF, row ? (int64_t)t : LPX_NOIDX};
+        th = wave_argmin(th); // first argmin (:165-166)
+        const int r = __builtin_amdgcn_readfirstlane((int)th.i);
+        const double dr = tb_readlane(d, r);
+        const double e = (t == r) ? 1.0 / dr : (-d) / dr; // :236-244 (lanes >= m: d = 0, e = -0, their rows stay 0)
+        const double em = (-rcj) / dr;                    // eliminates the entering column's reduced cost
+        const double xr = tb_readlane(xb, r);
+        if (row) xb = (t == r) ? e * xr : fma(e, xr, xb); // :251-253
+        const int64_t leaving = (int64_t)__builtin_amdgcn_readlane((int)bas, r); // variable ids < 2^31 here (n <= 128)
+        // this column's pivot-row entry
+        double pr = 0.0;
+        switch (r) {
+#define TB_GET(i) case (i): pr = x[(i)]; break;
+            TB_ROWS(TB_GET)
+#undef TB_GET
+        }
+        // E @ T: row_i += e_i * row_r for every row (e_i sits in lane i: broadcast as a scalar operand), then
+        // row_r = e_r * row_r (old) over it.  The entering variable's slot goes to the leaving variable, whose column is
+        // the eta column itself.
+        const bool mine = t == jl;
+#pragma unroll
+        for (int i = 0; i < TB_MAX; ++i) {
+            const double ei = tb_readlane(e, i);
+            // row r: fma onto -0.0 is the plain product e_r * row_r, bit for bit (r is uniform: a scalar select)
+            const double u = fma(ei, pr, (i == r) ? -0.0 : x[i]);
+            x[i] = mine ? ei : u;
+        }
+        rc = mine ? em : fma(em, pr, rc);
+        if (mine) var = leaving;
+        if (t == r) bas = jv; // :261
+        if (a.log && t == 0 && pivots < a.log_cap) {
+            int64_t *lg = a.log + (lp * a.log_cap + pivots) * 3;
+            lg[0] = r;
+            lg[1] = jv;
+            lg[2] = leaving;
+        }
+        pivots += 1;
+        f32 = false;
+    }
+
+    // ---- result: x = scatter(x_B), cost = dot(c, x) in index order (primal_solvers.py:72-79)
+    __syncthreads();
+    for (int j = t; j < n; j += 64) xs[j] = 0.0;
+    __syncthreads();
+    if (row) xs[bas] = xb;
+    __syncthreads();
+    for (int j = t; j < n; j += 64) a.x[lp * n + j] = xs[j];
+    if (row) a.basis[lp * m + t] = bas;
+    if (t == 0) {
+        double s1 = 0.0;
+        for (int jx = 0; jx < n; ++jx) s1 = fma((double)cf[jx], xs[jx], s1);
+        a.cost[lp] = s1;
+        a.status[lp] = status;
+        a.iters[lp] = counter;
+        a.pivots[lp] = pivots;
+    }
+}
+
+// PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (primal_solvers.py:176-263) in condensed tableau form.
+// m <= 64, n - m <= 64; starting basis = the slack block (columns n-m .. n-1 are the identity, b >= 0) with zero costs on
+// it -- the caller's check.  Arrays batch-major as in lpx_batched_primal_solve; basis is written (m per LP).
+extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                                         int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                                         int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap, void *stream)
+{
+    LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
+    LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
+    LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
+    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    TabBatchArgs a{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
+    hipLaunchKernelGGL(k_batched_tab, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}

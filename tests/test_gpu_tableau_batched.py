@@ -342,3 +342,55 @@ def test_tableau_without_nonbasic_columns_falls_back_to_the_full_layout():
     r = PrimalRevisedSimplexSolver(c, A, b, basis).solve()
     assert t.optimum and r.optimum and t.iters == r.iters == 1
     assert np.allclose(t.x, r.x, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n", [(4, 8), (5, 12), (16, 32), (37, 100), (40, 104), (64, 128), (61, 125), (64, 70)])
+def test_batched_tableau_kernel_bit_identical_to_the_tableau_oracle(m, n):
+    """lpx_batched_tableau_solve (condensed tableau in registers, one wave per LP): per LP the pivot log, x, cost, basis and
+    iters of the oracle's tableau loop, bit for bit, on full solves and on solves cut off by maxiters; the revised-form
+    batched kernel takes the same pivots and agrees in x to 1e-9."""
+    from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_primal(m, n, 300 + s) for s in range(6)]
+    args = [np.stack([p[k] for p in probs]) for k in range(4)]
+    for maxiters in (100000, 7):
+        tab = BatchedTableauSolver(*args, log_cap=4096)
+        rt = tab.solve(maxiters)
+        rev = BatchedPrimalSolver(*args, log_cap=4096)
+        rr = rev.solve(maxiters)
+        for i, p in enumerate(probs):
+            o = O.OracleTableau(*p, log_cap=4096).solve(maxiters)
+            assert tab.pivot_logs()[i].tolist() == o.log.tolist() == rev.pivot_logs()[i].tolist()
+            assert rt[i].iters == o.iters and rt[i].optimum == (o.status == O.OPTIMAL)
+            assert np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
+            assert rt[i].basis.tolist() == o.basis.tolist()
+            assert_close(rt[i].x, rr[i].x, "x vs the revised-form kernel")
+
+
+def test_batched_tableau_kernel_reference_sequences_and_unbounded():
+    from linprog_amd.batched import BatchedTableauSolver
+    from linprog_amd import _lib
+
+    golden = {cs["seed"]: cs["ref"] for cs in load("random.json")
+              if cs.get("gen") == "gen_primal" and cs["m"] == 64 and cs["n"] == 128 and cs["maxiters"] == 100000
+              and cs["solver"] == "PrimalRevisedSimplexSolver"}
+    assert golden
+    seeds = sorted(golden)
+    probs = [gen.gen_primal(64, 128, s) for s in seeds]
+    solver = BatchedTableauSolver(*[np.stack([p[k] for p in probs]) for k in range(4)], log_cap=2048)
+    res = solver.solve(100000)
+    for i, s in enumerate(seeds):
+        assert solver.pivot_logs()[i].tolist() == golden[s]["pivots"]
+        assert res[i].iters == golden[s]["iters"] and res[i].optimum
+        assert_close(res[i].x, golden[s]["x"], "x")
+        assert_close(res[i].cost, golden[s]["cost"], "cost")
+    # an unbounded LP in the batch (its structural columns negated) does not disturb its neighbours
+    c, A, b, basis = [np.stack([p[k] for p in probs[:3]]) for k in range(4)]
+    A[1, :, :64] *= -1
+    sol = BatchedTableauSolver(c, A, b, basis)
+    out = sol.solve(100000)
+    assert sol.raw["status"].tolist() == [_lib.OPTIMAL, _lib.PRIMAL_UNBOUNDED, _lib.OPTIMAL]
+    assert np.array_equal(out[0].x, res[0].x) and np.array_equal(out[2].x, res[2].x)
+    with pytest.raises(ValueError):
+        BatchedTableauSolver(c, A, b, basis[:, ::-1].copy())
