@@ -450,8 +450,11 @@ def bench_batch(args, rank, world, group):
     import torch.distributed as dist
 
     from linprog_amd import problems
-    from linprog_amd.batched import BatchedPrimalSolver
+    from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver
 
+    # carried state per LP: the condensed tableau in registers (default) or B^-1 in LDS (LPX_BATCH_FORM=revised)
+    tableau_form = os.environ.get("LPX_BATCH_FORM", "tableau") != "revised"
+    Batched = BatchedTableauSolver if tableau_form else BatchedPrimalSolver
     per_gpu = 4096
     seeds = range(rank * per_gpu, (rank + 1) * per_gpu)
     probs = [problems.gen_primal(64, 128, s) for s in seeds]
@@ -459,7 +462,7 @@ def bench_batch(args, rank, world, group):
     # long LPs running alone on a mostly idle chip) is covered by the head of the next.  Every step is still one full
     # pass over one batch of 4096 LPs with its own inputs and outputs.
     args4 = [np.stack([p[k] for p in probs]) for k in range(4)]
-    solvers = [BatchedPrimalSolver(*args4) for _ in range(2)]
+    solvers = [Batched(*args4) for _ in range(2)]
     streams = [torch.cuda.Stream() for _ in range(2)]
     solver = solvers[0]
     basis0 = solver.basis.clone()
@@ -492,19 +495,23 @@ def bench_batch(args, rank, world, group):
     # the "algorithmic bytes" of a pivot by the tableau formula, 16 (m+1)(n+1) B; the state is LDS-resident
     # by design, so this rate is not HBM traffic and may exceed the HBM peak.  `traffic` is the honest HBM figure: one load
     # of (A, b, c, basis) and one store of (x, basis, cost, status, iters, pivots) per LP and launch.
-    alg = 16.0 * (m + 1) * (n + 1) * piv * world * args.steps / dt / 1e9
+    ncarry = n - m if tableau_form else n  # the tableau kernel carries the nonbasic columns only
+    alg = 16.0 * (m + 1) * (ncarry + 1) * piv * world * args.steps / dt / 1e9
     hbm_per_launch = per_gpu * (4.0 * (m * n + m + n) + 8 * m + 8.0 * n + 8 * m + 8 + 4 + 8 + 8)
     out = {"metric": "batched LPs solved/sec (m=64 n=128)", "value": per_gpu * world * args.steps / dt, "unit": "LPs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "4096 x gen_primal(64,128,seed) per GPU, full solves (maxiters 100000), one wave per LP; consecutive batches "
                                   "alternate between two streams",
+                      "form": "condensed tableau in registers (lpx_batched_tableau_solve)" if tableau_form
+                      else "revised form, B^-1 in LDS (lpx_batched_primal_solve)",
                       "pivots_per_step_per_gpu": piv, "all_optimal": ok,
                       "pivots_per_s": piv * world * args.steps / dt},
-           "roofline": {"bound": "hbm", "kernel": "k_batched_wave", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "k_batched_tab" if tableau_form else "k_batched_wave", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / HBM_PEAK_GBS, "traffic": hbm_per_launch,
-                        "note": "LDS-resident solver state: 'achieved' is the tableau-formula byte count of SURVEY 8(d), "
-                                "served from LDS and registers, not HBM; 'traffic' is the HBM bytes one launch really moves"}}
+                        "note": "register/LDS-resident solver state: 'achieved' is the tableau-formula byte count of SURVEY 8(d) for the "
+                                "carried columns, served from registers and LDS, not HBM; 'traffic' is the HBM bytes one launch "
+                                "really moves"}}
     if rank == 0 and (args.cpu_pivots is None or args.cpu_pivots > 0):
         # the whole rank-0 batch through the oracle, one LP per core: CPU baseline and bit-exact parity gate in one
         from oracle import oracle as O
@@ -519,17 +526,29 @@ def bench_batch(args, rank, world, group):
             dc += time.perf_counter() - t1
             reps += 1
         res = solver.results()
-        same = (np.array_equal(res["x"], r["x"]) and np.array_equal(res["cost"], r["cost"])
-                and np.array_equal(res["basis"], r["basis"]) and np.array_equal(res["iters"], r["iters"]))
+        if tableau_form:
+            # same pivots as the revised-form oracle on every LP (basis, iteration count), x and cost to 1e-9; and bit for
+            # bit the oracle's TABLEAU loop, LP by LP (single thread, Python loop: a sample of 512)
+            same = (np.array_equal(res["basis"], r["basis"]) and np.array_equal(res["iters"], r["iters"])
+                    and np.allclose(res["x"], r["x"], rtol=1e-9, atol=1e-9) and np.allclose(res["cost"], r["cost"], rtol=1e-9, atol=1e-9))
+            for i in range(0, per_gpu, per_gpu // 512):
+                o = O.OracleTableau(*probs[i], log_cap=4).solve(100000)
+                same = same and np.array_equal(res["x"][i], o.x) and res["cost"][i] == o.cost and res["iters"][i] == o.iters
+            how = (f"basis and iters of all {per_gpu} LPs identical to the revised-form oracle's, x and cost within 1e-9; x, cost and "
+                   f"iters of 512 sampled LPs bit-identical to the oracle's tableau loop")
+        else:
+            same = (np.array_equal(res["x"], r["x"]) and np.array_equal(res["cost"], r["cost"])
+                    and np.array_equal(res["basis"], r["basis"]) and np.array_equal(res["iters"], r["iters"]))
+            how = f"x, cost, basis and iters of all {per_gpu} LPs bit-identical to the GPU's"
         if not same:
             sys.exit("bench invalid: batched GPU results differ from the oracle's on the same batch")
         if world == 1:
             out["cpu_baseline"] = {"value": per_gpu * reps / dc, "unit": "LPs/s", "cores": cores, "kind": "port",
                                    "sample": f"the same {per_gpu} LPs x {reps} passes, oracle revised loop (C), one LP per "
                                              f"OpenMP thread",
-                                   "parity": f"x, cost, basis and iters of all {per_gpu} LPs bit-identical to the GPU's"}
+                                   "parity": how}
         else:
-            out["parity"] = f"x, cost, basis and iters of rank 0's {per_gpu} LPs bit-identical to the oracle's"
+            out["parity"] = "rank 0: " + how
     if rank == 0:
         emit(out)
     if world > 1:
