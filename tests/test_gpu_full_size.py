@@ -67,15 +67,16 @@ def test_config4_tableau_invariants():
     assert o.log.tolist() == log[:kc].tolist()
 
 
-def test_config3_batch_full_size():
-    from linprog_amd.batched import BatchedPrimalSolver
+@pytest.mark.parametrize("form", ["tableau", "revised"])
+def test_config3_batch_full_size(form):
+    from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver
     from oracle import oracle as O
 
     B = 4096
     probs = [gen.gen_primal(64, 128, s) for s in range(B)]
     c = np.stack([p[0] for p in probs]); A = np.stack([p[1] for p in probs])
     b = np.stack([p[2] for p in probs]); basis = np.stack([p[3] for p in probs])
-    solver = BatchedPrimalSolver(c, A, b, basis)
+    solver = (BatchedTableauSolver if form == "tableau" else BatchedPrimalSolver)(c, A, b, basis)
     res = solver.solve(100000)
     raw = solver.raw
     assert (raw["status"] == 1).all() and (raw["iters"] == raw["pivots"] + 1).all()
@@ -91,8 +92,9 @@ def test_config3_batch_full_size():
     y = np.linalg.solve(np.transpose(Bm, (0, 2, 1)), cB[..., None])[..., 0]
     rc = c32 - np.einsum("bi,bij->bj", y, A32)
     assert rc.min() >= -1e-8 - 1e-9
-    for i in range(0, B, 293):  # a spread sample is bit-identical to the oracle
-        o = O.OracleRevised(*probs[i], log_cap=4).solve(100000)
+    Oracle = O.OracleTableau if form == "tableau" else O.OracleRevised
+    for i in range(0, B, 293):  # a spread sample is bit-identical to the oracle of the same form
+        o = Oracle(*probs[i], log_cap=4).solve(100000)
         assert np.array_equal(res[i].x, o.x) and res[i].cost == o.cost and res[i].iters == o.iters
 
 
