@@ -38,7 +38,9 @@ struct TabBatchArgs {
     int64_t log_cap;
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batched_tab(TabBatchArgs a)
+// MR = rows carried per lane (m rounded up to 16): smaller LPs do proportionally less work and fit more waves per SIMD
+template <int MR>
+__global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
 {
     __shared__ double dcol[TB_MAX + 2];
     __shared__ double xs[2 * TB_MAX];
@@ -49,9 +51,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const bool col = t < k, row = t < m;
     const float *A = a.A + lp * a.m * a.n;
 
-    double x[TB_MAX];
+    double x[MR];
 #pragma unroll
-    for (int i = 0; i < TB_MAX; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * n + t] : 0.0;
+    for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * n + t] : 0.0;
     double rc = col ? (double)a.c[lp * n + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
     double xb = row ? (double)a.b[lp * m + t] : 0.0;
     int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // the entering column goes from registers of one lane to one entry per lane: through LDS
         if (t == jl) {
 #pragma unroll
-            for (int i = 0; i < TB_MAX; ++i) dcol[i] = x[i];
+            for (int i = 0; i < MR; ++i) dcol[i] = x[i];
         }
         const double rcj = tb_readlane(rc, jl);
         __syncthreads();
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // this column's pivot-row entry
         double pr = 0.0;
         switch (r) {
-#define TB_GET(i) case (i): pr = x[(i)]; break;
+#define TB_GET(i) case (i): if constexpr ((i) < MR) pr = x[(i) < MR ? (i) : 0]; break;
             TB_ROWS(TB_GET)
 #undef TB_GET
         }
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // the eta column itself.
         const bool mine = t == jl;
 #pragma unroll
-        for (int i = 0; i < TB_MAX; ++i) {
+        for (int i = 0; i < MR; ++i) {
             const double ei = tb_readlane(e, i);
             // row r: fma onto -0.0 is the plain product e_r * row_r, bit for bit (r is uniform: a scalar select)
             const double u = fma(ei, pr, (i == r) ? -0.0 : x[i]);
@@ -153,7 +155,12 @@ extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, co
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
     TabBatchArgs a{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
-    hipLaunchKernelGGL(k_batched_tab, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)batch), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (m <= 16) hipLaunchKernelGGL(k_batched_tab<16>, grid, block, 0, st, a);
+    else if (m <= 32) hipLaunchKernelGGL(k_batched_tab<32>, grid, block, 0, st, a);
+    else if (m <= 48) hipLaunchKernelGGL(k_batched_tab<48>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_batched_tab<64>), grid, block, 0, st, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }
