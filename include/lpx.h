@@ -291,6 +291,11 @@ int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k, const flo
 int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                               int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                               int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
+/* The same for min c.x s.t. G x <= h, x >= 0 (preprocessing.py:17-69's [G | I] with its slack basis): G is m x k, c has k
+ * entries, h >= 0, m <= 64, k <= 64; the identity block is never stored.  Results carry all k + m variables, slacks last. */
+int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
+                                   int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
+                                   int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
 
 /* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
 /* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:

@@ -142,9 +142,17 @@ class BatchedTableauSolver(BatchedPrimalSolver):
         if self.m > 64 or k > 64:
             raise ValueError("BatchedTableauSolver: m <= 64 and n - m <= 64")
 
+    @classmethod
+    def from_inequalities(cls, c, G, h, log_cap=0):
+        self = super().from_inequalities(c, G, h, log_cap=log_cap)
+        if self.m > 64 or self.ineq_k > 64:
+            raise ValueError("BatchedTableauSolver: m <= 64 and k <= 64")
+        return self
+
     def enqueue(self, maxiters):
-        _lib.check(self.lib.lpx_batched_tableau_solve(
-            self.B, self.m, self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),
+        f = self.lib.lpx_batched_tableau_solve_ineq if self.ineq_k else self.lib.lpx_batched_tableau_solve
+        _lib.check(f(
+            self.B, self.m, self.ineq_k if self.ineq_k else self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),
             self.x.data_ptr(), self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(), self.pivots.data_ptr(),
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
 

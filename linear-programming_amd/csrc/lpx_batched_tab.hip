@@ -36,6 +36,7 @@ struct TabBatchArgs {
     int64_t maxiters;
     int64_t *log;
     int64_t log_cap;
+    int64_t na; // stored columns of A and entries of c per LP: n, or n - m for the inequality form (G and its costs only)
 };
 
 // MR = rows carried per lane (m rounded up to 16): smaller LPs do proportionally less work and fit more waves per SIMD
@@ -49,16 +50,17 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     const int64_t lp = blockIdx.x;
     const int m = (int)a.m, n = (int)a.n, k = n - m;
     const bool col = t < k, row = t < m;
-    const float *A = a.A + lp * a.m * a.n;
+    const int na = (int)a.na;
+    const float *A = a.A + lp * a.m * a.na;
 
     double x[MR];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * n + t] : 0.0;
-    double rc = col ? (double)a.c[lp * n + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+    for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * na + t] : 0.0;
+    double rc = col ? (double)a.c[lp * na + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
     double xb = row ? (double)a.b[lp * m + t] : 0.0;
     int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
     int64_t bas = row ? (int64_t)(k + t) : -1;  // basis[t]
-    for (int j = t; j < n; j += 64) cf[j] = a.c[lp * n + j];
+    for (int j = t; j < n; j += 64) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
 
     bool f32 = true; // the first ratio test divides in float32
     int32_t status = LPX_RUNNING;
@@ -143,6 +145,18 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     }
 }
 
+static int tab_launch(const TabBatchArgs &a, void *stream)
+{
+    const dim3 grid((unsigned)a.batch), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.m <= 16) hipLaunchKernelGGL(k_batched_tab<16>, grid, block, 0, st, a);
+    else if (a.m <= 32) hipLaunchKernelGGL(k_batched_tab<32>, grid, block, 0, st, a);
+    else if (a.m <= 48) hipLaunchKernelGGL(k_batched_tab<48>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_batched_tab<64>, grid, block, 0, st, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 // PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (primal_solvers.py:176-263) in condensed tableau form.
 // m <= 64, n - m <= 64; starting basis = the slack block (columns n-m .. n-1 are the identity, b >= 0) with zero costs on
 // it -- the caller's check.  Arrays batch-major as in lpx_batched_primal_solve; basis is written (m per LP).
@@ -154,13 +168,18 @@ extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, co
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
-    TabBatchArgs a{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap};
-    const dim3 grid((unsigned)batch), block(64);
-    hipStream_t st = (hipStream_t)stream;
-    if (m <= 16) hipLaunchKernelGGL(k_batched_tab<16>, grid, block, 0, st, a);
-    else if (m <= 32) hipLaunchKernelGGL(k_batched_tab<32>, grid, block, 0, st, a);
-    else if (m <= 48) hipLaunchKernelGGL(k_batched_tab<48>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_batched_tab<64>), grid, block, 0, st, a);
-    LPX_LAUNCH_CHECK();
-    return LPX_OK;
+    return tab_launch(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
+}
+
+// min c.x s.t. G x <= h, x >= 0 per LP (the [G | I] standard form of preprocessing.py:17-69 with its slack basis): G is
+// m x k, c has k entries, h >= 0; the identity block is never stored or read.  Results carry all k + m variables.
+extern "C" int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
+                                              int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                                              int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap, void *stream)
+{
+    LPX_REQUIRE(batch > 0 && m > 0 && k > 0 && maxiters >= 0, "bad sizes");
+    LPX_REQUIRE(G && h && c && basis && x && cost && status && iters && pivots, "null pointer");
+    LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
+    LPX_REQUIRE(m <= TB_MAX && k <= TB_MAX, "m <= 64 and k <= 64 (one lane per row and per structural column)");
+    return tab_launch(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k}, stream);
 }

@@ -394,3 +394,22 @@ def test_batched_tableau_kernel_reference_sequences_and_unbounded():
     assert np.array_equal(out[0].x, res[0].x) and np.array_equal(out[2].x, res[2].x)
     with pytest.raises(ValueError):
         BatchedTableauSolver(c, A, b, basis[:, ::-1].copy())
+
+
+@pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 60)])
+def test_batched_tableau_inequality_form_equals_materialised_problem(m, k):
+    """lpx_batched_tableau_solve_ineq (G x <= h; the slack identity is never stored) returns the same bits as the
+    standard-form entry point on [G | I]."""
+    from linprog_amd.batched import BatchedTableauSolver
+
+    probs = [gen.gen_primal(m, k + m, 70 + s) for s in range(4)]
+    c = np.stack([p[0] for p in probs]); A = np.stack([p[1] for p in probs]); b = np.stack([p[2] for p in probs])
+    basis = np.stack([p[3] for p in probs])
+    full = BatchedTableauSolver(c, A, b, basis, log_cap=2048)
+    rf = full.solve(100000)
+    ineq = BatchedTableauSolver.from_inequalities(c[:, :k], A[:, :, :k], b, log_cap=2048)
+    ri = ineq.solve(100000)
+    for i in range(4):
+        assert ineq.pivot_logs()[i].tolist() == full.pivot_logs()[i].tolist()
+        assert np.array_equal(ri[i].x, rf[i].x) and ri[i].cost == rf[i].cost and ri[i].iters == rf[i].iters
+        assert ri[i].basis.tolist() == rf[i].basis.tolist() and ri[i].optimum
