@@ -106,15 +106,17 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         // E @ T: row_i += e_i * row_r for every row (e_i sits in lane i: broadcast as a scalar operand), then
         // row_r = e_r * row_r (old) over it.  The entering variable's slot goes to the leaving variable, whose column is
         // the eta column itself.
+        // One select per element covers both special cases: the pivot row (every lane) and the entering lane (every row)
+        // take their addend from -0.0 -- fma(e_r, row_r, -0.0) is the plain product, and with the entering lane's
+        // multiplicand set to 1 fma(e_i, 1, -0.0) is e_i itself, bit for bit.
         const bool mine = t == jl;
+        const double prs = mine ? 1.0 : pr;
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const double ei = tb_readlane(e, i);
-            // row r: fma onto -0.0 is the plain product e_r * row_r, bit for bit (r is uniform: a scalar select)
-            const double u = fma(ei, pr, (i == r) ? -0.0 : x[i]);
-            x[i] = mine ? ei : u;
+            x[i] = fma(ei, prs, (mine || i == r) ? -0.0 : x[i]);
         }
-        rc = mine ? em : fma(em, pr, rc);
+        rc = fma(em, prs, mine ? -0.0 : rc);
         if (mine) var = leaving;
         if (t == r) bas = jv; // :261
         if (a.log && t == 0 && pivots < a.log_cap) {
