@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         th = wave_argmin(th); // first argmin (:165-166)
         const int r = __builtin_amdgcn_readfirstlane((int)th.i);
         const double dr = tb_readlane(d, r);
-        const double e = (t == r) ? 1.0 / dr : (-d) / dr; // :236-244 (lanes >= m: d = 0, e = -0, their rows stay 0)
+        const double e = ((t == r) ? 1.0 : -d) / dr; // :236-244: 1/d_r or (-d_i)/d_r (lanes >= m: d = 0, e = -0, rows stay 0)
         const double em = (-rcj) / dr;                    // eliminates the entering column's reduced cost
         const double xr = tb_readlane(xb, r);
         if (row) xb = (t == r) ? e * xr : fma(e, xr, xb); // :251-253
