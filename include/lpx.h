@@ -296,6 +296,12 @@ int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *
 int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
                                    int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                                    int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
+/* DualRevisedSimplexSolver per LP (dual_solvers.py:82-120) with the same carried state.  A, b as preprocessing.py:6-15 leaves
+ * them (rows with b < 0 flipped): the slack block then has +-1 on its diagonal and is the starting basis (B^-1 = B), its
+ * costs are 0 and c >= 0 elsewhere (dual feasible, :14-16) -- the caller's checks.  m <= 64, n - m <= 64. */
+int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                                   int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
+                                   int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
 
 /* ------------------------------------------------- individual kernels (unit-tested against the oracle) */
 /* Rank-1 pivot update M[i,:] += e_i * M_old[r,:] (i != r), M[r,:] = e_r * M_old[r,:]:

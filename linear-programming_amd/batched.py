@@ -157,6 +157,31 @@ class BatchedTableauSolver(BatchedPrimalSolver):
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
 
 
+class BatchedDualTableauSolver(BatchedDualSolver):
+    """``DualRevisedSimplexSolver`` per LP with the condensed tableau as carried state (``lpx_batched_tableau_dual_solve``).
+    Starting basis: the slack block, +-identity after preprocessing flipped the rows with b < 0, with zero costs; dual
+    feasibility is checked per LP as in ``BatchedDualSolver``.  Bit-identical to the oracle's dual tableau loop."""
+
+    def __init__(self, c, A, b, basis, log_cap=0):
+        super().__init__(c, A, b, basis, log_cap=log_cap)
+        k = self.n - self.m
+        A32 = self.A.cpu().numpy()
+        blk = A32[:, :, k:]
+        diag = blk[:, np.arange(self.m), np.arange(self.m)]
+        if (not np.array_equal(np.asarray(basis), np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
+                or np.count_nonzero(blk) != self.B * self.m or not np.all(np.abs(diag) == 1.0)
+                or np.any(self.c.cpu().numpy()[:, k:] != 0)):
+            raise ValueError("BatchedDualTableauSolver starts from the slack basis (+-identity columns n-m..n-1, zero costs)")
+        if self.m > 64 or k > 64:
+            raise ValueError("BatchedDualTableauSolver: m <= 64 and n - m <= 64")
+
+    def enqueue(self, maxiters):
+        _lib.check(self.lib.lpx_batched_tableau_dual_solve(
+            self.B, self.m, self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),
+            self.x.data_ptr(), self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(), self.pivots.data_ptr(),
+            int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
+
+
 def solve_many(problems, maxiters=100):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
     launches of different shapes run on separate streams, results come back in input order."""

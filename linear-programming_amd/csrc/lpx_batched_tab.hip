@@ -40,7 +40,9 @@ struct TabBatchArgs {
 };
 
 // MR = rows carried per lane (m rounded up to 16): smaller LPs do proportionally less work and fit more waves per SIMD
-template <int MR>
+// DUAL: the dual simplex rules (dual_solvers.py:47-108) on the same carried state; the starting basis is then the slack
+// block with +-1 on its diagonal (-1 where preprocessing flipped a row with b < 0), x_B = B^-1 b may be negative.
+template <int MR, bool DUAL>
 __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
 {
     __shared__ double dcol[TB_MAX + 2];
@@ -55,9 +57,14 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
 
     double x[MR];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)A[(int64_t)i * na + t] : 0.0;
+    for (int i = 0; i < MR; ++i) {
+        // B^-1 of a +-identity basis is itself: row i of B^-1 A is row i of A times B_ii (exact)
+        const double sg = (DUAL && i < m) ? (double)A[(int64_t)i * na + k + i] : 1.0;
+        x[i] = (col && i < m) ? sg * (double)A[(int64_t)i * na + t] : 0.0;
+    }
     double rc = col ? (double)a.c[lp * na + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
     double xb = row ? (double)a.b[lp * m + t] : 0.0;
+    if (DUAL && row) xb *= (double)A[(int64_t)t * na + k + t];
     int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
     int64_t bas = row ? (int64_t)(k + t) : -1;  // basis[t]
     for (int j = t; j < n; j += 64) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
@@ -67,14 +74,41 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     int64_t counter = 0, pivots = 0;
     while (counter < a.maxiters) {
         counter += 1;
-        const bool neg = col && rc < 0.0;
-        // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (primal_solvers.py:140-142) <=> no rc below -1e-8
-        if (__ballot(neg) == 0 || __ballot(col && rc < -LPX_ATOL) == 0) {
-            status = LPX_OPTIMAL;
-            break;
+        int r, jl;
+        int64_t jv;
+        double d, dr, pr = 0.0;
+        if (!DUAL) {
+            const bool neg = col && rc < 0.0;
+            // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (primal_solvers.py:140-142) <=> no rc below -1e-8
+            if (__ballot(neg) == 0 || __ballot(col && rc < -LPX_ATOL) == 0) {
+                status = LPX_OPTIMAL;
+                break;
+            }
+            jv = wave_imin(neg ? var : LPX_NOIDX); // first negative index, by variable id (:135-138)
+            jl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(var == jv)) - 1);
+        } else {
+            const bool negx = row && xb < 0.0;
+            // optimal <=> min x_B >= 0 or |min x_B| <= 1e-8 (dual_solvers.py:52-54); leaving row = first x_B < 0 (:47-50)
+            const unsigned long long nb = __ballot(negx);
+            if (nb == 0 || __ballot(row && xb < -LPX_ATOL) == 0) {
+                status = LPX_OPTIMAL;
+                break;
+            }
+            r = __builtin_amdgcn_readfirstlane(__ffsll((long long)nb) - 1);
+            switch (r) { // this column's entry of the dual row B^-1[r,:] A (:37-38)
+#define TB_GET(i) case (i): if constexpr ((i) < MR) pr = x[(i) < MR ? (i) : 0]; break;
+                TB_ROWS(TB_GET)
+#undef TB_GET
+            }
+            if (__ballot(col && pr < 0.0) == 0) { // min(row) >= 0 (:56-59)
+                status = LPX_DUAL_UNBOUNDED;
+                break;
+            }
+            VI th{col ? lpx_dsd(rc, pr, f32) : LPX_INF, col ? var : LPX_NOIDX};
+            th = wave_argmin(th); // first argmin of (-rc_j) / row_j over row_j < 0, by variable id (:61-80)
+            jv = th.i;
+            jl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(var == jv)) - 1);
         }
-        const int64_t jv = wave_imin(neg ? var : LPX_NOIDX); // first negative index, by variable id (:135-138)
-        const int jl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(var == jv)) - 1);
         // the entering column goes from registers of one lane to one entry per lane: through LDS
         if (t == jl) {
 #pragma unroll
@@ -82,30 +116,30 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         }
         const double rcj = tb_readlane(rc, jl);
         __syncthreads();
-        const double d = row ? dcol[t] : 0.0;
-        if (__ballot(row && d > 0.0) == 0) { // max(d) <= 0 (:144-147)
-            status = LPX_PRIMAL_UNBOUNDED;
-            break;
+        d = row ? dcol[t] : 0.0;
+        if (!DUAL) {
+            if (__ballot(row && d > 0.0) == 0) { // max(d) <= 0 (:144-147)
+                status = LPX_PRIMAL_UNBOUNDED;
+                break;
+            }
+            VI th{row ? lpx_psd(xb, d, f32) : LPX_INF, row ? (int64_t)t : LPX_NOIDX};
+            th = wave_argmin(th); // first argmin (:165-166)
+            r = __builtin_amdgcn_readfirstlane((int)th.i);
         }
-        VI th{row ? lpx_psd(xb, d, f32) : LPX_INF, row ? (int64_t)t : LPX_NOIDX};
-        th = wave_argmin(th); // first argmin (:165-166)
-        const int r = __builtin_amdgcn_readfirstlane((int)th.i);
-        const double dr = tb_readlane(d, r);
+        dr = tb_readlane(d, r);
         const double e = ((t == r) ? 1.0 : -d) / dr; // :236-244: 1/d_r or (-d_i)/d_r (lanes >= m: d = 0, e = -0, rows stay 0)
-        const double em = (-rcj) / dr;                    // eliminates the entering column's reduced cost
+        const double em = (-rcj) / dr;               // eliminates the entering column's reduced cost
         const double xr = tb_readlane(xb, r);
         if (row) xb = (t == r) ? e * xr : fma(e, xr, xb); // :251-253
         const int64_t leaving = (int64_t)__builtin_amdgcn_readlane((int)bas, r); // variable ids < 2^31 here (n <= 128)
-        // this column's pivot-row entry
-        double pr = 0.0;
-        switch (r) {
+        __syncthreads();
+        if (!DUAL) { // this column's pivot-row entry
+            switch (r) {
 #define TB_GET(i) case (i): if constexpr ((i) < MR) pr = x[(i) < MR ? (i) : 0]; break;
-            TB_ROWS(TB_GET)
+                TB_ROWS(TB_GET)
 #undef TB_GET
+            }
         }
-        // E @ T: row_i += e_i * row_r for every row (e_i sits in lane i: broadcast as a scalar operand), then
-        // row_r = e_r * row_r (old) over it.  The entering variable's slot goes to the leaving variable, whose column is
-        // the eta column itself.
         // One select per element covers both special cases: the pivot row (every lane) and the entering lane (every row)
         // take their addend from -0.0 -- fma(e_r, row_r, -0.0) is the plain product, and with the entering lane's
         // multiplicand set to 1 fma(e_i, 1, -0.0) is e_i itself, bit for bit.
@@ -147,14 +181,15 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     }
 }
 
+template <bool DUAL>
 static int tab_launch(const TabBatchArgs &a, void *stream)
 {
     const dim3 grid((unsigned)a.batch), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (a.m <= 16) hipLaunchKernelGGL(k_batched_tab<16>, grid, block, 0, st, a);
-    else if (a.m <= 32) hipLaunchKernelGGL(k_batched_tab<32>, grid, block, 0, st, a);
-    else if (a.m <= 48) hipLaunchKernelGGL(k_batched_tab<48>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(k_batched_tab<64>, grid, block, 0, st, a);
+    if (a.m <= 16) hipLaunchKernelGGL((k_batched_tab<16, DUAL>), grid, block, 0, st, a);
+    else if (a.m <= 32) hipLaunchKernelGGL((k_batched_tab<32, DUAL>), grid, block, 0, st, a);
+    else if (a.m <= 48) hipLaunchKernelGGL((k_batched_tab<48, DUAL>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_batched_tab<64, DUAL>), grid, block, 0, st, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }
@@ -170,7 +205,7 @@ extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, co
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
-    return tab_launch(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
+    return tab_launch<false>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
 }
 
 // min c.x s.t. G x <= h, x >= 0 per LP (the [G | I] standard form of preprocessing.py:17-69 with its slack basis): G is
@@ -183,5 +218,19 @@ extern "C" int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(G && h && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && k <= TB_MAX, "m <= 64 and k <= 64 (one lane per row and per structural column)");
-    return tab_launch(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k}, stream);
+    return tab_launch<false>(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k}, stream);
+}
+
+// DualRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (dual_solvers.py:82-120) in condensed tableau form.
+// A and b as preprocessing.py:6-15 leaves them (rows with b < 0 flipped); the starting basis is the slack block, whose
+// diagonal is then +-1, with zero costs on it and c >= 0 elsewhere (dual feasible, :14-16) -- the caller's checks.
+extern "C" int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
+                                              int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
+                                              int64_t *pivots, int64_t maxiters, int64_t *log, int64_t log_cap, void *stream)
+{
+    LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
+    LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
+    LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
+    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    return tab_launch<true>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
 }

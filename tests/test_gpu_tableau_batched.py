@@ -413,3 +413,25 @@ def test_batched_tableau_inequality_form_equals_materialised_problem(m, k):
         assert ineq.pivot_logs()[i].tolist() == full.pivot_logs()[i].tolist()
         assert np.array_equal(ri[i].x, rf[i].x) and ri[i].cost == rf[i].cost and ri[i].iters == rf[i].iters
         assert ri[i].basis.tolist() == rf[i].basis.tolist() and ri[i].optimum
+
+
+@pytest.mark.parametrize("m,n", [(8, 16), (13, 40), (32, 64), (37, 100), (64, 128), (60, 124)])
+def test_batched_dual_tableau_kernel_bit_identical_to_the_dual_tableau_oracle(m, n):
+    """lpx_batched_tableau_dual_solve: per LP the pivot log, x, cost, basis, iters and status of the oracle's dual tableau
+    loop, bit for bit; the revised-form dual kernel takes the same pivots."""
+    from linprog_amd.batched import BatchedDualSolver, BatchedDualTableauSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_dual(m, n, 400 + s) for s in range(5)]
+    args = [np.stack([p[k] for p in probs]) for k in range(4)]
+    for maxiters in (100000, 9):
+        tab = BatchedDualTableauSolver(*args, log_cap=2048)
+        rt = tab.solve(maxiters)
+        rev = BatchedDualSolver(*args, log_cap=2048)
+        rev.solve(maxiters)
+        for i, p in enumerate(probs):
+            o = O.OracleTableau(*p, kind="dual", log_cap=2048).solve(maxiters)
+            assert tab.pivot_logs()[i].tolist() == o.log.tolist() == rev.pivot_logs()[i].tolist()
+            assert rt[i].iters == o.iters and rt[i].optimum is (True if o.status == O.OPTIMAL else None)
+            assert np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
+            assert rt[i].basis.tolist() == o.basis.tolist()
