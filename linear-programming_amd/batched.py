@@ -182,9 +182,11 @@ class BatchedDualTableauSolver(BatchedDualSolver):
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
 
 
-def solve_many(problems, maxiters=100):
+def solve_many(problems, maxiters=100, form="revised"):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
-    launches of different shapes run on separate streams, results come back in input order."""
+    launches of different shapes run on separate streams, results come back in input order.  ``form="tableau"``: groups
+    that qualify (slack start, m <= 64, n - m <= 64) go through the faster condensed-tableau kernel, whose x and cost
+    agree with the revised form's to 1e-9 (same pivots) rather than bit for bit."""
     torch = torch_cuda()
     groups = {}
     for idx, (c, A, b, basis) in enumerate(problems):
@@ -195,7 +197,15 @@ def solve_many(problems, maxiters=100):
         st = torch.cuda.Stream()
         st.wait_stream(main)
         with torch.cuda.stream(st):
-            s = BatchedPrimalSolver(*[np.stack([np.asarray(problems[i][k]) for i in idxs]) for k in range(4)])
+            args = [np.stack([np.asarray(problems[i][k]) for i in idxs]) for k in range(4)]
+            s = None
+            if form == "tableau":
+                try:
+                    s = BatchedTableauSolver(*args)
+                except ValueError:  # not a slack start or too large for a wave: the revised-form kernels take it
+                    s = None
+            if s is None:
+                s = BatchedPrimalSolver(*args)
             s.enqueue(maxiters)
         solvers.append((idxs, s, st))
     out = [None] * len(problems)

@@ -279,6 +279,10 @@ def test_solve_many_mixed_shapes():
     for p, r in zip(probs, res):
         o = O.OracleRevised(*p, log_cap=4).solve(100000)
         assert r.optimum and r.iters == o.iters and np.array_equal(r.x, o.x) and r.cost == o.cost
+    fast = solve_many(probs, 100000, form="tableau")  # (80, 170) does not fit a wave: it stays on the generic kernel
+    for r, f in zip(res, fast):
+        assert f.optimum and f.iters == r.iters and f.basis.tolist() == r.basis.tolist()
+        assert_close(f.x, r.x, "x")
 
 
 @pytest.mark.parametrize("m,n", [(8, 16), (13, 40), (32, 64), (37, 100), (64, 128), (64, 256), (60, 150)])
