@@ -439,3 +439,31 @@ def test_batched_dual_tableau_kernel_bit_identical_to_the_dual_tableau_oracle(m,
             assert rt[i].iters == o.iters and rt[i].optimum is (True if o.status == O.OPTIMAL else None)
             assert np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
             assert rt[i].basis.tolist() == o.basis.tolist()
+
+
+def test_batched_tableau_kernel_on_degenerate_goldens():
+    """Ties in the ratio test and equal reduced costs (small-integer data, zeros in b): "first index" decides the pivots
+    (primal_solvers.py:137, :166).  Every degenerate golden through the tableau batched kernel: the reference's pivot
+    sequence, basis, iters, x and cost; unbounded cases report the status."""
+    from linprog_amd import _lib
+    from linprog_amd.batched import BatchedTableauSolver
+
+    cases = [cs for cs in load("degenerate.json") if cs["solver"] == "PrimalRevisedSimplexSolver"]
+    shapes = sorted({(cs["m"], cs["n"]) for cs in cases})
+    assert len(cases) >= 12
+    for m, n in shapes:
+        grp = [cs for cs in cases if (cs["m"], cs["n"]) == (m, n)]
+        probs = [problem_of(cs) for cs in grp]
+        solver = BatchedTableauSolver(*[np.stack([p[k] for p in probs]) for k in range(4)], log_cap=8192)
+        res = solver.solve(grp[0].get("maxiters", 100))
+        for i, cs in enumerate(grp):
+            ref = cs["ref"]
+            assert cs.get("maxiters", 100) == grp[0].get("maxiters", 100)
+            assert solver.pivot_logs()[i].tolist() == ref["pivots"], (m, n, cs["seed"])
+            if ref["exception"] == "PrimalIsUnboundedError":
+                assert solver.raw["status"][i] == _lib.PRIMAL_UNBOUNDED
+                continue
+            assert not ref["exception"]
+            assert res[i].iters == ref["iters"] and res[i].optimum == ref["optimum"] and res[i].basis.tolist() == ref["basis"]
+            assert_close(res[i].x, ref["x"], "x")
+            assert_close(res[i].cost, ref["cost"], "cost")
