@@ -132,7 +132,6 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         const double xr = tb_readlane(xb, r);
         if (row) xb = (t == r) ? e * xr : fma(e, xr, xb); // :251-253
         const int64_t leaving = (int64_t)__builtin_amdgcn_readlane((int)bas, r); // variable ids < 2^31 here (n <= 128)
-        __syncthreads();
         if (!DUAL) { // this column's pivot-row entry
             switch (r) {
 #define TB_GET(i) case (i): if constexpr ((i) < MR) pr = x[(i) < MR ? (i) : 0]; break;
