@@ -129,18 +129,39 @@ class BatchedDualSolver(BatchedPrimalSolver):
 class BatchedTableauSolver(BatchedPrimalSolver):
     """The same per-LP semantics with the condensed tableau as carried state (``lpx_batched_tableau_solve``): one rank-1
     update per pivot instead of three chains of m dependent fmas, the tableau in registers.  Bit-identical to the oracle's
-    tableau loop; the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64, slack starting basis
-    with zero basic costs (what ``from_inequalities`` and every synthetic config start from)."""
+    tableau loop; the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64.  From the slack basis with
+    zero basic costs (``from_inequalities``, every synthetic config) the kernel reads A itself; from any other primal
+    feasible basis the float32 starting tableau is formed on the host as the reference's constructor would."""
 
     def __init__(self, c, A, b, basis, log_cap=0):
-        super().__init__(c, A, b, basis, log_cap=log_cap)
+        super().__init__(c, A, b, basis, log_cap=log_cap)  # preprocessing, feasibility check (primal_solvers.py:41-53)
         k = self.n - self.m
-        c32 = np.asarray(c).astype(np.float32)
-        if (self.Binv0 is not None or not np.array_equal(np.asarray(basis), np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
-                or np.any(c32[:, k:] != 0)):
-            raise ValueError("BatchedTableauSolver starts from the slack basis (identity columns n-m..n-1, zero costs)")
         if self.m > 64 or k > 64:
             raise ValueError("BatchedTableauSolver: m <= 64 and n - m <= 64")
+        c32 = np.asarray(c).astype(np.float32)
+        basis = np.asarray(basis).astype(np.int64)
+        self.start = None
+        slack = (self.Binv0 is None and np.array_equal(basis, np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
+                 and not np.any(c32[:, k:] != 0))
+        if not slack:
+            # any other start: the reference's float32 constructor state (:37-38, :64) carried as a condensed tableau,
+            # formed per LP on the host with the reference's own NumPy expressions
+            A32, b32 = self.A.cpu().numpy(), self.b.cpu().numpy()
+            T0 = np.empty((self.B, self.m, k), dtype=np.float32)
+            rc0 = np.empty((self.B, k), dtype=np.float32)
+            xb0 = np.empty((self.B, self.m), dtype=np.float32)
+            var0 = np.empty((self.B, k), dtype=np.int64)
+            for i in range(self.B):
+                inv32 = np.linalg.inv(A32[i][:, basis[i]])
+                nb = np.setdiff1d(np.arange(self.n), basis[i])
+                if nb.size != k:
+                    raise ValueError("a basis needs m distinct columns")
+                var0[i] = nb
+                T0[i] = (inv32 @ A32[i])[:, nb]
+                rc0[i] = (c32[i] - c32[i][basis[i]] @ inv32 @ A32[i])[nb]
+                xb0[i] = inv32 @ b32[i]
+            self.start = tuple(to_device(np.ascontiguousarray(v)) for v in (T0, rc0, xb0, var0))
+            self.basis0 = self.basis.clone()
 
     @classmethod
     def from_inequalities(cls, c, G, h, log_cap=0):
@@ -150,6 +171,14 @@ class BatchedTableauSolver(BatchedPrimalSolver):
         return self
 
     def enqueue(self, maxiters):
+        if getattr(self, "start", None) is not None:
+            T0, rc0, xb0, var0 = self.start
+            self.basis.copy_(self.basis0)  # input and output of the kernel: every solve starts from the constructor's basis
+            _lib.check(self.lib.lpx_batched_tableau_solve_from(
+                self.B, self.m, self.n, T0.data_ptr(), rc0.data_ptr(), xb0.data_ptr(), var0.data_ptr(), self.c.data_ptr(),
+                self.basis.data_ptr(), self.x.data_ptr(), self.cost.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
+                self.pivots.data_ptr(), int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
+            return
         f = self.lib.lpx_batched_tableau_solve_ineq if self.ineq_k else self.lib.lpx_batched_tableau_solve
         _lib.check(f(
             self.B, self.m, self.ineq_k if self.ineq_k else self.n, self.A.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), self.basis.data_ptr(),

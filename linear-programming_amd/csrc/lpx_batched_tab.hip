@@ -37,6 +37,11 @@ struct TabBatchArgs {
     int64_t *log;
     int64_t log_cap;
     int64_t na; // stored columns of A and entries of c per LP: n, or n - m for the inequality form (G and its costs only)
+    // general starting basis (else NULL): the starting tableau itself, formed by the caller with the reference's float32
+    // expressions (primal_solvers.py:37-38, :64) -- T0 = (inv(A_B) A)[:, nonbasic] (m x k per LP), its reduced costs, x_B and
+    // the variable of every column slot; basis is then an input as well
+    const float *T0, *rc0, *xb0;
+    const int64_t *var0;
 };
 
 // MR = rows carried per lane (m rounded up to 16): smaller LPs do proportionally less work and fit more waves per SIMD
@@ -55,18 +60,28 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     const int na = (int)a.na;
     const float *A = a.A + lp * a.m * a.na;
 
+    const bool from_T0 = !DUAL && a.T0 != nullptr; // wave-uniform: the caller supplies the starting tableau (A, b unused)
     double x[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         // B^-1 of a +-identity basis is itself: row i of B^-1 A is row i of A times B_ii (exact)
         const double sg = (DUAL && i < m) ? (double)A[(int64_t)i * na + k + i] : 1.0;
-        x[i] = (col && i < m) ? sg * (double)A[(int64_t)i * na + t] : 0.0;
+        x[i] = (col && i < m && !from_T0) ? sg * (double)A[(int64_t)i * na + t] : 0.0;
     }
-    double rc = col ? (double)a.c[lp * na + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
-    double xb = row ? (double)a.b[lp * m + t] : 0.0;
+    double rc = (col && !from_T0) ? (double)a.c[lp * na + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+    double xb = (row && !from_T0) ? (double)a.b[lp * m + t] : 0.0;
     if (DUAL && row) xb *= (double)A[(int64_t)t * na + k + t];
     int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
     int64_t bas = row ? (int64_t)(k + t) : -1;  // basis[t]
+    if (from_T0) {
+        const float *T0 = a.T0 + lp * a.m * k;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)T0[(int64_t)i * k + t] : 0.0;
+        rc = col ? (double)a.rc0[lp * k + t] : 0.0;
+        xb = row ? (double)a.xb0[lp * m + t] : 0.0;
+        var = col ? a.var0[lp * k + t] : LPX_NOIDX;
+        bas = row ? a.basis[lp * m + t] : -1;
+    }
     for (int j = t; j < n; j += 64) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
 
     bool f32 = true; // the first ratio test divides in float32
@@ -204,7 +219,7 @@ extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, co
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
-    return tab_launch<false>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
+    return tab_launch<false>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
 // min c.x s.t. G x <= h, x >= 0 per LP (the [G | I] standard form of preprocessing.py:17-69 with its slack basis): G is
@@ -217,7 +232,7 @@ extern "C" int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(G && h && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && k <= TB_MAX, "m <= 64 and k <= 64 (one lane per row and per structural column)");
-    return tab_launch<false>(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k}, stream);
+    return tab_launch<false>(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
 // DualRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (dual_solvers.py:82-120) in condensed tableau form.
@@ -231,5 +246,23 @@ extern "C" int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
     LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
-    return tab_launch<true>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n}, stream);
+    return tab_launch<true>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+// lpx_batched_tableau_solve from ANY primal feasible starting basis: the caller passes the starting tableau (see
+// TabBatchArgs: T0 m x k, rc0 k, xb0 m, var0 k per LP, all float32-valued as the reference's constructor state) and the
+// basis (input and output).  c (n per LP) is only needed for the cost of the result.
+extern "C" int lpx_batched_tableau_solve_from(int64_t batch, int64_t m, int64_t n, const float *T0, const float *rc0,
+                                              const float *xb0, const int64_t *var0, const float *c, int64_t *basis, double *x,
+                                              double *cost, int32_t *status, int64_t *iters, int64_t *pivots, int64_t maxiters,
+                                              int64_t *log, int64_t log_cap, void *stream)
+{
+    LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
+    LPX_REQUIRE(T0 && rc0 && xb0 && var0 && c && basis && x && cost && status && iters && pivots, "null pointer");
+    LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
+    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    // A and b are not read in this mode: T0 / xb0 stand in so that the unused pointers stay valid
+    return tab_launch<false>(TabBatchArgs{batch, m, n, T0, xb0, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, T0, rc0,
+                                          xb0, var0},
+                             stream);
 }

@@ -397,7 +397,7 @@ def test_batched_tableau_kernel_reference_sequences_and_unbounded():
     assert sol.raw["status"].tolist() == [_lib.OPTIMAL, _lib.PRIMAL_UNBOUNDED, _lib.OPTIMAL]
     assert np.array_equal(out[0].x, res[0].x) and np.array_equal(out[2].x, res[2].x)
     with pytest.raises(ValueError):
-        BatchedTableauSolver(c, A, b, basis[:, ::-1].copy())
+        BatchedTableauSolver(*[np.stack([p[k] for p in [gen.gen_primal(70, 140, 0)]]) for k in range(4)])  # m > 64
 
 
 @pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 60)])
@@ -467,3 +467,33 @@ def test_batched_tableau_kernel_on_degenerate_goldens():
             assert res[i].iters == ref["iters"] and res[i].optimum == ref["optimum"] and res[i].basis.tolist() == ref["basis"]
             assert_close(res[i].x, ref["x"], "x")
             assert_close(res[i].cost, ref["cost"], "cost")
+
+
+@pytest.mark.parametrize("m,n", [(5, 12), (16, 32), (37, 100), (64, 128)])
+def test_batched_tableau_kernel_from_a_general_starting_basis(m, n):
+    """lpx_batched_tableau_solve_from: any primal feasible starting basis (here the basis after 9 oracle pivots; one LP of
+    the batch starts from a permuted slack basis).  The float32 constructor state of the reference (primal_solvers.py:37-38,
+    :64) is carried as a condensed tableau: same arithmetic as the unbatched condensed tableau solver (bit-identical x,
+    cost, pivots), the reference's (revised-form) pivot sequence, x to float32 accuracy of the start."""
+    from linprog_amd.batched import BatchedTableauSolver
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    probs = []
+    for s_ in range(5):
+        c, A, b, basis = gen.gen_primal(m, n, 500 + s_)
+        mid = basis[::-1].copy() if s_ == 0 else O.OracleRevised(c, A, b, basis, log_cap=16).solve(9).basis.copy()
+        probs.append((c, A, b, mid))
+    solver = BatchedTableauSolver(*[np.stack([p[k] for p in probs]) for k in range(4)], log_cap=4096)
+    assert solver.start is not None
+    for maxiters in (100000, 6):
+        res = solver.solve(maxiters)
+        for i, p in enumerate(probs):
+            ref = O.OracleRevised(*p, log_cap=4096).solve(maxiters)
+            one = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": 4096})(*p, condensed=True)
+            r1 = one.solve(maxiters)
+            assert solver.pivot_logs()[i].tolist() == one.pivot_log().tolist() == ref.log.tolist()
+            assert np.array_equal(res[i].x, r1.x) and res[i].iters == r1.iters and res[i].basis.tolist() == r1.basis.tolist()
+            assert abs(res[i].cost - r1.cost) <= 1e-13 * max(1.0, abs(r1.cost))  # tree dot there, sequential here
+            assert res[i].optimum == (ref.status == O.OPTIMAL)
+            assert np.allclose(res[i].x, ref.x, rtol=1e-5, atol=1e-5)
