@@ -316,6 +316,15 @@ int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t n, const fl
  * _update_inv_basis_matrix / _update_bfs, primal_solvers.py:247-253.  rowr_scratch: >= ld doubles. */
 int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
                      double *rowr_scratch, void *stream);
+/* lpx_pivot_update for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code that may not
+ * call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation -- and so cannot
+ * bring a rowr_scratch.  The copy of the old pivot row lives in a file-scope device array inside liblpx
+ * (LPX_STATIC_ROW_MAX = 65536 doubles = 512 KiB per GPU, held until the process ends); the call allocates nothing, on
+ * the device or through any library.  Same kernels and the same bits as lpx_pivot_update.  ld > 65536 returns
+ * LPX_E_SIZE (use lpx_pivot_update then).  All calls on one GPU share the array: calls that overlap on one GPU (two
+ * streams, two host threads) race on it -- serialise them on one stream. */
+#define LPX_STATIC_ROW_MAX 65536
+int lpx_pivot_update_static(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e, void *stream);
 /* Eta column, primal_solvers.py:235-244: e_i = (-d_i)/d_r, e_r = 1/d_r. */
 int lpx_eta(const double *d, int64_t m, int64_t r, double *e, void *stream);
 /* primal_solvers.py:135-142: out_val[0] = min(rc), out_idx[0] = first j with rc_j<0 (or -1).

@@ -102,6 +102,7 @@ _SIGS = {
     "lpx_batched_tableau_dual_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_batched_tableau_solve_from": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_pivot_update": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, vp]),
+    "lpx_pivot_update_static": (C.c_int, [vp, i64, i64, i64, i64, vp, vp]),
     "lpx_eta": (C.c_int, [vp, i64, i64, vp, vp]),
     "lpx_reduce_scratch_bytes": (i64, []),
     "lpx_price_first_negative": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),

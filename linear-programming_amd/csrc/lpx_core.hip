@@ -1411,6 +1411,61 @@ extern "C" int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t l
     return LPX_OK;
 }
 
+// The same update for callers that cannot allocate (no counterpart in the reference): the copy of the old pivot row, which
+// lpx_pivot_update keeps in the caller's rowr_scratch, lives in a file-scope device array.  Each GPU holds its own copy of
+// the array at its own address; the host-side name `scratch` is only a handle for hipGetSymbolAddress, so the device
+// address is looked up once per device (with that device current) and only that pointer is ever handed to a kernel.
+// Every call on a GPU shares the array: calls that overlap on one GPU (two streams, two threads) race on it.
+// LPX_STATIC_ROW_MAX (lpx.h) doubles: 512 KiB per GPU, held until the process ends
+#define LPX_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[LPX_STATIC_ROW_MAX];
+static std::mutex g_static_mu;
+static double *g_static_row[LPX_STATIC_MAX_DEVICES];
+
+static int static_row_scratch(double **out)
+{
+    int dev = -1;
+    LPX_HIP(hipGetDevice(&dev));
+    LPX_REQUIRE(dev >= 0 && dev < LPX_STATIC_MAX_DEVICES, "device index beyond the per-device table");
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (g_static_row[dev] == nullptr) {
+        void *p = nullptr;
+        LPX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        LPX_REQUIRE(p != nullptr && lpx_aligned16(p), "static scratch has no usable device address");
+        g_static_row[dev] = (double *)p;
+    }
+    *out = g_static_row[dev];
+    return LPX_OK;
+}
+
+extern "C" int lpx_pivot_update_static(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e,
+                                       void *stream)
+{
+    LPX_REQUIRE(M && e, "null pointer");
+    LPX_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld % 2) == 0, "ld must be >= cols and even");
+    LPX_REQUIRE(r >= 0 && r < rows, "pivot row out of range");
+    LPX_REQUIRE(lpx_aligned16(M), "M must be 16-byte aligned");
+    if (ld > LPX_STATIC_ROW_MAX) {
+        lpx_set_error("lpx_pivot_update_static: ld = %lld exceeds the static pivot-row buffer of %d doubles; use "
+                      "lpx_pivot_update with a caller-owned rowr_scratch",
+                      (long long)ld, LPX_STATIC_ROW_MAX);
+        return LPX_E_SIZE;
+    }
+    double *rowr = nullptr;
+    int rc = static_row_scratch(&rowr);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // the whole row of the last call's contents that this call reads is overwritten first: nothing to clear
+    hipLaunchKernelGGL(k_copy_row, dim3((unsigned)lpx_cdiv(ld, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st,
+                       (const double *)(M + r * ld), rowr, ld);
+    Rank1Args a{};
+    a.M = M; a.rows = rows; a.cols = cols; a.ld = ld; a.e = e; a.rowr = rowr; a.r = r; a.ctrl = nullptr;
+    const Rank1Plan p = lpx_rank1_plan(rows, cols);
+    lpx_rank1_launch<false>(p, a, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 __global__ __launch_bounds__(LPX_BLOCK) void k_eta(const double *d, int64_t m, int64_t r, double *e)
 {
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
