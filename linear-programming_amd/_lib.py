@@ -53,7 +53,7 @@ class LpxTableau(C.Structure):
         ("T", vp), ("basis", vp), ("var_state", vp), ("ctrl", vp),
         ("log", vp), ("log_cap", i64),
         ("workspace", vp), ("workspace_bytes", i64),
-        ("slot_var", vp), ("var_slot", vp),
+        ("slot_var", vp), ("var_slot", vp), ("T_alt", vp),
     ]
 
 

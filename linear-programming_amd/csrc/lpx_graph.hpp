@@ -28,8 +28,11 @@ LpxGraphCache &lpx_graph_cache();
 
 static inline int lpx_graph_unroll()
 {
+    // always even: the single-launch tableau chain alternates two buffers with the parity of the iteration, and a
+    // replayed graph must end on the parity it started from
     int u = lpx_env_int("LPX_GRAPH_UNROLL", 16);
-    return u < 1 ? 1 : (u > 256 ? 256 : u);
+    u = u < 2 ? 2 : (u > 256 ? 256 : u);
+    return u + (u & 1);
 }
 
 // enqueue_one(stream) enqueues exactly one iteration.  Returns LPX_OK or an error code.

@@ -14,9 +14,24 @@
 #include "lpx_rank1.hpp"
 #include "lpx_graph.hpp"
 
+// ratio-test partial of the single-launch chain: one record per lookahead workgroup (<= TF_MAXLA)
+#define TF_MAXLA 64
+struct FusedPart {
+    double *th;    // min ratio over the workgroup's rows
+    int64_t *row;  // first row attaining it (LPX_NOIDX: none)
+    double *dmax;  // max of the entering column over the rows
+    double *dbest; // entering-column entry of that row (the pivot element if it wins)
+    int64_t *bvar; // basic variable of that row
+};
 struct TabWs {
     double *d, *e, *rowr, *scal;
     Partials price, ratio;
+    // single-launch chain (k_t_fused): everything a launch reads was written by the launch before it, so the entering
+    // column, the ratio partials and the entering decision exist twice and alternate with the parity of the pivot
+    double *d2[2];
+    FusedPart fp[2];
+    double *next[2]; // {min rc, entering variable, its column slot, optimal?}
+    int64_t *base;   // pivots at the start of the current lpx_tableau_iterate call
     int64_t bytes;
 };
 static inline char *tcarve(char *&p, int64_t bytes)
@@ -42,6 +57,16 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
     w.scal = (double *)tcarve(p, 8 * 16);
     tcarve_partials(p, w.price);
     tcarve_partials(p, w.ratio);
+    for (int q = 0; q < 2; ++q) {
+        w.d2[q] = (double *)tcarve(p, 8 * (m + 2));
+        w.fp[q].th = (double *)tcarve(p, 8 * TF_MAXLA);
+        w.fp[q].row = (int64_t *)tcarve(p, 8 * TF_MAXLA);
+        w.fp[q].dmax = (double *)tcarve(p, 8 * TF_MAXLA);
+        w.fp[q].dbest = (double *)tcarve(p, 8 * TF_MAXLA);
+        w.fp[q].bvar = (int64_t *)tcarve(p, 8 * TF_MAXLA);
+        w.next[q] = (double *)tcarve(p, 8 * 8);
+    }
+    w.base = (int64_t *)tcarve(p, 8 * 2);
     w.bytes = (int64_t)(p - (char *)base);
     return w;
 }
@@ -447,6 +472,432 @@ __global__ __launch_bounds__(T_SMALL_THREADS) void k_t_pre_small(lpx_tableau s, 
         ctrl->f32_phase = 0;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Single-launch pivot chain for tableaus that are launch-bound rather than HBM-bound (BASELINE config 2: 1000 x 2000).
+// The three-kernel chain above costs three launches of ~5 us for 16 MB of traffic.  Here ONE launch does a whole pivot:
+//   * the tableau ping-pongs between two buffers (T and T_alt): a launch reads Tin and writes Tout, so the old pivot row
+//     and every old column stay readable for the whole launch -- no pivot-row copy, no eta array (e_i = -d_i / d_r is
+//     formed per row on the fly), no in-place race;
+//   * a few extra "lookahead" workgroups, placed first in the grid, work on the NEXT pivot while the others stream the
+//     update: they form the reduced-cost row the update is about to write (same expressions, bit for bit), price it
+//     (primal_solvers.py:135-142), form that entering column and x_B as the update will leave them, and run the ratio
+//     test (:149-167) over their rows.  Their records (entering decision, column, per-workgroup ratio partials) are what
+//     the next launch starts from: its workgroups combine the <= 64 partials in their prologue (uniform loads).
+// So the kernel boundary is the only grid-wide synchronisation of a pivot.  A launch never reads what it writes: the
+// records alternate between two copies with the pivot's parity `par`, a kernel ARGUMENT (the host enqueues iteration t
+// of a call with par = t & 1; launches after a terminal status are no-ops, so host and device parity cannot drift; the
+// hipGraph unroll is even).  A bootstrap launch (BOOT) prices the carried row itself at the start of every call, and
+// a final launch copies T_alt back to T when the call ends on odd parity, so every other entry point finds the state in T.
+// ---------------------------------------------------------------------------------------------------------
+#define TF_THREADS 256
+#define TF_UN 4
+struct FusedArgs {
+    lpx_tableau s;
+    const double *Tin;
+    double *Tout;
+    FusedPart Rc, Rn;     // ratio partials of this pivot (read) / of the next one (written)
+    const double *dc;     // entering column of this pivot, m+1 entries (dc[m] = its reduced cost)
+    double *dn;
+    const double *nc;     // entering decision of this pivot
+    double *nn;
+    int64_t *base;
+    int64_t nla;          // lookahead workgroups = cdiv(m + 1, TF_THREADS)
+    int64_t nstrips;      // column strips of 2 * TF_THREADS columns
+    int64_t rpb;          // rows per update workgroup
+};
+
+// lookahead workgroup q: pricing of the next reduced-cost row (whole row, every lookahead workgroup redundantly), then the
+// next entering column and the ratio partial over rows [q * TF_THREADS, (q+1) * TF_THREADS).  BOOT: the state in Tin is
+// priced as it is (no pending update); r, dr, j, k, leaving are then unused.
+// The kernels below are latency chains: what they cost is the number of DEPENDENT global-memory round trips on the
+// longest path (tools/launch_floor.hip: ~2.1 us for an empty launch in a replayed graph, +0.3-0.4 us per dependent
+// trip, +1.2 us for the 8 MB stream beside it).  So every load whose address does not depend on this pivot's leaving
+// row is issued in the first instructions of the kernel, before the status test (all those addresses are valid
+// whatever the status), reductions are one DPP wave reduction + one LDS exchange, and loops over memory are unrolled
+// in batches whose loads all go out before the first use.
+// -DLPX_TF_STAMPS: diagnostic build, lookahead workgroup 0 prints where its time goes (100 MHz ticks since kernel start)
+#ifdef LPX_TF_STAMPS
+__device__ long long g_tf_t0;
+__device__ long long g_tf_stamp[16];
+#define LPX_TF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tf_stamp[k] = (long long)wall_clock64() - g_tf_t0; } while (0)
+#else
+#define LPX_TF_STAMP(k) do { } while (0)
+#endif
+struct TfPrice {
+    double v;     // min reduced cost (first-negative rule) / the candidate's reduced cost (Dantzig)
+    int64_t var;  // entering candidate: variable id
+    int64_t slot; // its column in T
+};
+struct TfRatio {
+    double th;    // min ratio
+    int64_t i;    // first row attaining it
+    double dv;    // entering-column entry of that row
+    int64_t bv;   // its basic variable
+    double dmax;  // max of the entering column
+};
+__device__ __forceinline__ int64_t tf_readlane_i64(int64_t v, int lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffLL), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double tf_readlane_f64(double v, int lane)
+{
+    return __longlong_as_double(tf_readlane_i64(__double_as_longlong(v), lane));
+}
+__device__ __forceinline__ TfRatio tf_ratio_op(TfRatio x, TfRatio y);
+// Wave reduction of ratio records whose row indices ASCEND with the lane (lanes without a row hold th = +inf, i = NOIDX
+// and come last): the first lane attaining the wave's minimum ratio is the first argmin (np.argmin, primal_solvers.py:166),
+// so only the ratio itself (2 dwords) and max(d) go through DPP; the rest is read from the winning lane.
+__device__ __forceinline__ TfRatio tf_wave_ratio(TfRatio t)
+{
+    const double mn = wave_min(t.th);
+    const double dmax = wave_max(t.dmax);
+    const unsigned long long who = __ballot(t.th == mn); // never empty: +inf == +inf (no NaN: d > 0 is checked first)
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+    return TfRatio{mn, tf_readlane_i64(t.i, src), tf_readlane_f64(t.dv, src), tf_readlane_i64(t.bv, src), dmax};
+}
+__device__ __forceinline__ TfRatio tf_ratio_op(TfRatio x, TfRatio y)
+{
+    TfRatio u = vi_less(y.th, y.i, x.th, x.i) ? y : x;
+    u.dmax = fmax(x.dmax, y.dmax);
+    return u;
+}
+// round trip 1 of a lookahead workgroup: its rows' x_B, basic variables and current entering-column entries, and the
+// first batch of the reduced-cost row with the variable ids of its slots
+struct TfLaPre {
+    double xi, dci, dcm;
+    int64_t bsi;
+    double rcm[TF_UN];
+    int64_t var[TF_UN];
+};
+template <bool BOOT>
+__device__ __forceinline__ TfLaPre tf_la_preload(const FusedArgs &a, int64_t q)
+{
+    const lpx_tableau &s = a.s;
+    const int64_t m = s.m, n = s.n, ld = s.ld;
+    const int64_t i = q * TF_THREADS + threadIdx.x;
+    TfLaPre p;
+    p.xi = (i <= m) ? a.Tin[i * ld + n] : 0.0;
+    p.dci = (!BOOT && i <= m) ? a.dc[i] : 0.0;
+    p.dcm = BOOT ? 0.0 : a.dc[m];
+    p.bsi = (i < m) ? s.basis[i] : -1;
+#pragma unroll
+    for (int u = 0; u < TF_UN; ++u) {
+        const int64_t c = threadIdx.x + (int64_t)u * TF_THREADS;
+        p.rcm[u] = (c < n) ? a.Tin[m * ld + c] : LPX_INF;
+        p.var[u] = (c >= n) ? LPX_NOIDX : (s.slot_var ? s.slot_var[c] : s.col0 + c);
+    }
+    return p;
+}
+
+// lookahead workgroup q: pricing of the next reduced-cost row (whole row, every lookahead workgroup redundantly), then the
+// next entering column and the ratio partial over rows [q * TF_THREADS, (q+1) * TF_THREADS).  BOOT: the state in Tin is
+// priced as it is (no pending update); r, dr, j, k, leaving are then unused.
+template <bool BOOT>
+__device__ __forceinline__ void tf_lookahead(const FusedArgs &a, int64_t q, const TfLaPre &pre, int64_t r, double dr,
+                                             int64_t j, int64_t k, int64_t leaving, bool f32)
+{
+    __shared__ TfPrice shp[TF_THREADS / 64];
+    __shared__ TfRatio shr[TF_THREADS / 64];
+    const lpx_tableau &s = a.s;
+    const int64_t m = s.m, n = s.n, ld = s.ld;
+    const bool cond = s.slot_var != nullptr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double *Tin = a.Tin;
+    const bool dz = s.pricing == LPX_PRICE_DANTZIG;
+    const int64_t i = q * TF_THREADS + tid;
+    const bool in = i < m;
+    LPX_TF_STAMP(1);
+    // round trip 2 (not BOOT): the old pivot row under this thread's columns, and x_B[r]
+    const double xr = (!BOOT && i <= m) ? Tin[r * ld + n] : 0.0;
+    const int64_t bsi = (!BOOT && i == r) ? j : pre.bsi; // the basis as this pivot leaves it
+    const double em = BOOT ? 0.0 : (-pre.dcm) / dr;      // multiplier of the reduced-cost row (k_t_prepare's e[m])
+    TfPrice p{LPX_INF, LPX_NOIDX, -1};
+    for (int64_t c0 = tid; c0 < n; c0 += TF_THREADS * TF_UN) {
+        double pr[TF_UN], rcm[TF_UN];
+        int64_t var[TF_UN];
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t c = c0 + (int64_t)u * TF_THREADS;
+            const bool ok = c < n;
+            pr[u] = (ok && !BOOT) ? Tin[r * ld + c] : 0.0;
+            if (c0 == tid) { // first batch: loaded before the leaving row was known
+                rcm[u] = pre.rcm[u];
+                var[u] = pre.var[u];
+            } else {
+                rcm[u] = ok ? Tin[m * ld + c] : LPX_INF;
+                var[u] = !ok ? LPX_NOIDX : (cond ? s.slot_var[c] : s.col0 + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t c = c0 + (int64_t)u * TF_THREADS;
+            if (c >= n) continue;
+            double rc = rcm[u];
+            int64_t v = var[u];
+            if (!BOOT) {
+                if (c == k) { // the column the update rewrites as a whole: eta column (condensed) / unit vector (full)
+                    rc = cond ? em : 0.0;
+                    v = cond ? leaving : s.col0 + c;
+                } else {
+                    rc = fma(em, pr[u], rc);
+                }
+            }
+            if (dz) {
+                if (vi_less(rc, v, p.v, p.var)) p = TfPrice{rc, v, c};
+            } else {
+                p.v = fmin(p.v, rc);
+                if (rc < 0.0 && v < p.var) { p.var = v; p.slot = c; }
+            }
+        }
+    }
+    // wave reduction on the narrowest payloads: min rc (2 dwords), smallest negative variable id (2 dwords), then the
+    // slot from the lane that holds that id -- a struct reduction moves 6 dwords through every DPP step
+    const auto pop = [dz](TfPrice x, TfPrice y) {
+        if (dz) return vi_less(y.v, y.var, x.v, x.var) ? y : x;
+        TfPrice t = (y.var < x.var) ? y : x; // first negative index: smallest variable id
+        t.v = fmin(x.v, y.v);
+        return t;
+    };
+    LPX_TF_STAMP(2);
+    if (dz) {
+        p = wave_allreduce(p, pop);
+    } else {
+        const int64_t myvar = p.var;
+        p.v = wave_min(p.v);
+        p.var = wave_imin(myvar);
+        const unsigned long long who = __ballot(myvar == p.var); // variable ids are distinct; all lanes when none is negative
+        p.slot = tf_readlane_i64(p.slot, __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1));
+    }
+    LPX_TF_STAMP(3);
+    if (lane == 0) shp[wave] = p;
+    __syncthreads();
+    p = shp[0];
+#pragma unroll
+    for (int w = 1; w < TF_THREADS / 64; ++w) p = pop(p, shp[w]);
+    const int64_t kp = p.slot;
+    const bool opt = lpx_is_optimal_min(p.v);
+    if (q == 0 && tid == 0) {
+        a.nn[0] = p.v;
+        a.nn[1] = (double)p.var; // exact: ids < 2^53, LPX_NOIDX = 2^62
+        a.nn[2] = (double)kp;
+        a.nn[3] = opt ? 1.0 : 0.0;
+    }
+    LPX_TF_STAMP(4);
+    if (opt || kp < 0) return;
+    // round trip 3: the next entering column as the update will leave it
+    double dv = 0.0, xb = pre.xi;
+    if (i <= m) {
+        if (BOOT) {
+            dv = Tin[i * ld + kp];
+        } else {
+            const double ei = (i == r) ? 1.0 / dr : (-pre.dci) / dr; // primal_solvers.py:236-244
+            if (kp == k) dv = cond ? ei : ((i == r) ? 1.0 : 0.0);
+            else {
+                const double prk = Tin[r * ld + kp];
+                dv = (i == r) ? ei * prk : fma(ei, prk, Tin[i * ld + kp]);
+            }
+            xb = (i == r) ? ei * xr : fma(ei, xr, pre.xi); // :251-253
+        }
+        a.dn[i] = dv;
+    }
+    TfRatio t{in ? lpx_psd(xb, dv, f32) : LPX_INF, in ? i : LPX_NOIDX, dv, bsi, in ? dv : -LPX_INF};
+    LPX_TF_STAMP(5);
+    t = tf_wave_ratio(t);
+    LPX_TF_STAMP(6);
+    if (lane == 0) shr[wave] = t;
+    __syncthreads();
+    LPX_TF_STAMP(7);
+    if (tid == 0) {
+        t = shr[0];
+#pragma unroll
+        for (int w = 1; w < TF_THREADS / 64; ++w) t = tf_ratio_op(t, shr[w]);
+        a.Rn.th[q] = t.th;
+        a.Rn.row[q] = t.i;
+        a.Rn.dmax[q] = t.dmax;
+        a.Rn.dbest[q] = (t.i == LPX_NOIDX) ? 0.0 : t.dv;
+        a.Rn.bvar[q] = (t.i == LPX_NOIDX) ? -1 : t.bv;
+    }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_t_boot(FusedArgs a)
+{
+    lpx_ctrl *ctrl = a.s.ctrl;
+    const TfLaPre pre = tf_la_preload<true>(a, blockIdx.x);
+    const int32_t status = ctrl->status, f32 = ctrl->f32_phase;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.base = ctrl->pivots; // also when the loop has ended: k_t_syncback reads it
+    if (status != LPX_RUNNING) return;
+    tf_lookahead<true>(a, blockIdx.x, pre, 0, 1.0, 0, -1, 0, f32 != 0);
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_t_fused(FusedArgs a)
+{
+    const lpx_tableau &s = a.s;
+    lpx_ctrl *ctrl = s.ctrl;
+    const int64_t m = s.m, ld = s.ld;
+    const bool is_la = (int64_t)blockIdx.x < a.nla;
+    const bool is_book = blockIdx.x == gridDim.x - 1; // the last workgroup keeps the books
+#ifdef LPX_TF_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tf_t0 = (long long)wall_clock64();
+#endif
+    // ---- round trip 1: everything whose address does not depend on this pivot's leaving row
+    const int32_t status = ctrl->status;
+    const int64_t counter0 = ctrl->counter, pivots0 = ctrl->pivots; // used by the bookkeeper only
+    const double mn = a.nc[0], nj = a.nc[1], nk = a.nc[2], nopt = a.nc[3]; // entering decision of this pivot
+    TfRatio t{LPX_INF, LPX_NOIDX, 0.0, -1, -LPX_INF};
+    {   // ratio partials of this pivot: lane q of every wave loads partial q
+        const int q = threadIdx.x & 63;
+        if (q < a.nla) t = TfRatio{a.Rc.th[q], a.Rc.row[q], a.Rc.dbest[q], a.Rc.bvar[q], a.Rc.dmax[q]};
+    }
+    TfLaPre pre;
+    d2_t x[TF_UN];
+    double di[TF_UN];
+    int64_t row0 = 0, row1 = 0, col = 0;
+    bool live = false;
+    if (is_la) {
+        pre = tf_la_preload<false>(a, blockIdx.x);
+    } else if (!is_book) {
+        const uint32_t w = blockIdx.x - (uint32_t)a.nla; // 32-bit division: the grid has < 2^31 workgroups
+        const int64_t band = w / (uint32_t)a.nstrips, sx = w - (uint32_t)band * (uint32_t)a.nstrips;
+        row0 = band * a.rpb;
+        row1 = (row0 + a.rpb < m + 1) ? row0 + a.rpb : m + 1;
+        col = (sx * TF_THREADS + threadIdx.x) * 2;
+        live = col <= s.n; // columns 0 .. n (column n is x_B); ld is even, so the pair stays inside the row
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = row0 + u;
+            if (live && i < row1) {
+                x[u] = *(const d2_t *)(a.Tin + i * ld + col);
+                di[u] = a.dc[i];
+            }
+        }
+    }
+#ifdef LPX_TF_STAMPS
+    LPX_TF_STAMP(9);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LPX_TF_STAMP(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LPX_TF_STAMP(11);
+#endif
+    if (status != LPX_RUNNING) return;
+    const bool lead = is_book && threadIdx.x == 0;
+    const int64_t j = (int64_t)nj, k = (int64_t)nk;
+    if (nopt != 0.0) { // primal_solvers.py:195-198
+        if (lead) {
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            ctrl->status = LPX_OPTIMAL;
+        }
+        return;
+    }
+    // leaving row: first minimum ratio over the lookahead workgroups' partials (ascending row ranges)
+    t = tf_wave_ratio(t); // partial q covers rows [256 q, 256 q + 256): ascending with the lane
+    const double th = t.th, dmax = t.dmax, dr = t.dv;
+    const int64_t r = __builtin_amdgcn_readfirstlane((int)t.i), leaving = t.bv; // rows < 2^31 (m + 1 <= 16384)
+    if (dmax <= 0.0) { // primal_solvers.py:144-147
+        if (lead) {
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            ctrl->enter_j = j;
+            ctrl->aux_val = dmax;
+            ctrl->status = LPX_PRIMAL_UNBOUNDED;
+        }
+        return;
+    }
+    if (is_book) {
+        // bookkeeping of this pivot, by a workgroup of its own (in a lookahead workgroup its dependent loads and stores
+        // would sit on the critical path of the launch): nothing below is read by any workgroup of this launch
+        if (threadIdx.x == 0) {
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            ctrl->enter_j = j;
+            s.basis[r] = j; // primal_solvers.py:261
+            if (s.slot_var) {
+                s.slot_var[k] = leaving;
+                s.var_slot[leaving] = k;
+                s.var_slot[j] = -1;
+            } else {
+                const int64_t ll = leaving - s.col0;
+                if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
+                s.var_state[k] = LPX_VS_BASIC;
+            }
+            ctrl->enter_slot = k;
+            if (s.log && pivots0 < s.log_cap) {
+                s.log[3 * pivots0 + 0] = r;
+                s.log[3 * pivots0 + 1] = j;
+                s.log[3 * pivots0 + 2] = leaving;
+            }
+            ctrl->pivots = pivots0 + 1;
+            ctrl->leave_r = r;
+            ctrl->leave_var = leaving;
+            ctrl->ratio_val = th;
+            ctrl->aux_val = dmax;
+            ctrl->flip = 0;
+            ctrl->f32_phase = 0;
+        }
+        return;
+    }
+    if (is_la) {
+        tf_lookahead<false>(a, blockIdx.x, pre, r, dr, j, k, leaving, false);
+#ifdef LPX_TF_STAMPS
+        LPX_TF_STAMP(8);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ctrl->pivots >= 40 && ctrl->pivots < 46)
+            printf("tf stamps (10 ns): issued %lld scalar-done %lld vector-done %lld pre-r %lld | row-r loads+scan %lld | price dpp %lld | lds+decide %lld | col loads %lld | ratio dpp %lld | lds %lld | end %lld\n",
+                   g_tf_stamp[9], g_tf_stamp[10], g_tf_stamp[11], g_tf_stamp[1], g_tf_stamp[2], g_tf_stamp[3], g_tf_stamp[4], g_tf_stamp[5], g_tf_stamp[6], g_tf_stamp[7], g_tf_stamp[8]);
+#endif
+        return;
+    }
+    // ---- update workgroup: rows [row0, row1) x one strip of 2 * TF_THREADS columns, Tin -> Tout
+    if (!live) return;
+    const bool cond = s.slot_var != nullptr;
+    const d2_t pr = *(const d2_t *)(a.Tin + r * ld + col); // round trip 2: the old pivot row
+    const bool fix0 = col == k, fix1 = col + 1 == k;
+    for (int64_t i0 = row0; i0 < row1; i0 += TF_UN) { // TF_UN rows in flight
+        if (i0 != row0) {
+#pragma unroll
+            for (int u = 0; u < TF_UN; ++u) {
+                const int64_t i = i0 + u;
+                if (i < row1) {
+                    x[u] = *(const d2_t *)(a.Tin + i * ld + col);
+                    di[u] = a.dc[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = i0 + u;
+            if (i >= row1) break;
+            const bool isr = i == r;
+            const double ei = isr ? 1.0 / dr : (-di[u]) / dr; // :236-244, row m: eliminates rc_j
+            if (isr) {
+                x[u][0] = ei * pr[0];
+                x[u][1] = ei * pr[1];
+            } else {
+                x[u][0] = fma(ei, pr[0], x[u][0]);
+                x[u][1] = fma(ei, pr[1], x[u][1]);
+            }
+            if (fix0) x[u][0] = cond ? ei : (isr ? 1.0 : 0.0);
+            if (fix1) x[u][1] = cond ? ei : (isr ? 1.0 : 0.0);
+            *(d2_t *)(a.Tout + i * ld + col) = x[u];
+        }
+    }
+}
+
+// end of a call: the state belongs in T
+__global__ __launch_bounds__(LPX_BLOCK) void k_t_syncback(lpx_tableau s, const int64_t *base, const double *Talt, int64_t count)
+{
+    if (((s.ctrl->pivots - *base) & 1) == 0) return;
+    for (int64_t t = ((int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x) * 2; t < count; t += (int64_t)gridDim.x * LPX_BLOCK * 2)
+        *(d2_t *)(s.T + t) = *(const d2_t *)(Talt + t);
+}
+
+static inline bool t_use_fused(const lpx_tableau *s)
+{
+    if (s->T_alt == nullptr || lpx_env_int("LPX_TABLEAU_FUSED", 1) == 0) return false;
+    return lpx_cdiv(s->m + 1, TF_THREADS) <= TF_MAXLA && s->n + 1 <= 32768;
+}
 static inline bool t_is_small(const lpx_tableau *s)
 {
     if (lpx_env_int("LPX_TABLEAU_SMALL", 1) == 0) return false;
@@ -483,6 +934,67 @@ struct TabKey {
     int what;
 };
 
+
+static int tableau_iterate_fused(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st)
+{
+    LPX_REQUIRE(lpx_aligned16(s->T_alt), "T_alt must be 16-byte aligned");
+    FusedArgs a{};
+    a.s = *s;
+    a.base = w.base;
+    a.nla = lpx_cdiv(s->m + 1, TF_THREADS);
+    a.nstrips = lpx_cdiv(s->n + 1, 2 * TF_THREADS);
+    // tall update tiles amortise the per-workgroup prologue (kernel arguments, partials, pivot-row strip) as long as
+    // about one workgroup per CU remains: 1000 x 1000 on MI355X, rows per workgroup 1 / 4 / 8 / 16 / 32 -> 144 / 147 /
+    // 148.5 / 145 / 102 k pivots/s (tools/fused_sweep.sh)
+    int64_t rpb = lpx_env_int("LPX_FUSED_ROWS", 0);
+    if (rpb <= 0) {
+        rpb = 1;
+        while (rpb < 8 && a.nstrips * lpx_cdiv(s->m + 1, 2 * rpb) >= 240) rpb *= 2;
+    }
+    a.rpb = rpb;
+    const int64_t nupd = a.nstrips * lpx_cdiv(s->m + 1, rpb);
+    LPX_REQUIRE(a.nla + nupd + 1 < ((int64_t)1 << 31), "grid too large");
+    auto args_for = [&](int par) {
+        FusedArgs b = a;
+        b.Tin = par ? s->T_alt : s->T;
+        b.Tout = par ? s->T : s->T_alt;
+        b.Rc = w.fp[par]; b.Rn = w.fp[par ^ 1];
+        b.dc = w.d2[par]; b.dn = w.d2[par ^ 1];
+        b.nc = w.next[par]; b.nn = w.next[par ^ 1];
+        return b;
+    };
+    { // bootstrap: price the carried row, first entering column and ratio partials -> the records of parity 0
+        FusedArgs b = args_for(1); // writes the "next" side of parity 1 = parity 0's records ...
+        b.Tin = s->T;              // ... from the state in T
+        b.Tout = nullptr;
+        hipLaunchKernelGGL(k_t_boot, dim3((unsigned)a.nla), dim3(TF_THREADS), 0, st, b);
+    }
+    int64_t it = 0; // iteration index inside this call: parity of the launch
+    auto one = [&](hipStream_t q) {
+        const FusedArgs b = args_for((int)(it & 1));
+        lpx_k1_begin(q);
+        hipLaunchKernelGGL(k_t_fused, dim3((unsigned)(a.nla + nupd + 1)), dim3(TF_THREADS), 0, q, b);
+        lpx_k1_end(q);
+        it += 1;
+    };
+    struct {
+        lpx_tableau s;
+        int64_t rpb;
+        int what;
+    } key;
+    memset(&key, 0, sizeof key);
+    key.s = *s; key.rpb = rpb; key.what = 3;
+    const int rc = lpx_run_iterations(&key, sizeof key, iters, st, one);
+    const int64_t count = (s->m + 1) * s->ld;
+    int64_t nb = lpx_cdiv(count / 2, LPX_BLOCK);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_t_syncback, dim3((unsigned)nb), dim3(LPX_BLOCK), 0, st, *s, (const int64_t *)w.base,
+                       (const double *)s->T_alt, count);
+    if (rc) return rc;
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
     int rc = check_tableau(s);
@@ -490,10 +1002,11 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     LPX_REQUIRE(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n), "lpx_tableau_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
+    if (iters <= 0) return LPX_OK;
+    if (t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
     const int64_t nprice = plan.grid.x, nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
-    if (iters <= 0) return LPX_OK;
     // K1 refreshes the pricing partials of the NEXT iteration; the first iteration of a call scans the row itself
     t_launch_price(s, w, plan, st);
     const lpx_tableau sv = *s;

@@ -625,6 +625,62 @@ int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
     return s->status;
 }
 
+/* The same loop on the CONDENSED layout (the build's default for the carried tableau): T holds only the
+ * NONBASIC columns -- a basic column of a tableau is a unit vector whose pivot-row entry is 0, so the rank-1 update never
+ * changes it.  s->n counts column slots (column n is still x_B), slot_var[k] is the variable in slot k, var_state is
+ * unused.  Rules as in lpo_tableau_solve (primal_solvers.py:135-167): "first index with rc < 0" is the smallest
+ * VARIABLE id over the slots with a negative reduced cost; the optimality test reads the same values, since the reference
+ * forces basic reduced costs to exactly 0 (:65).  On a pivot the entering variable's slot is handed to the leaving
+ * variable, whose column after the update is the eta column itself (unit vector e_r updated: 0 + e_i * 1). */
+int lpo_tableau_solve_condensed(lpo_tableau *s, int64_t *slot_var, int64_t maxiters)
+{
+    const int64_t m = s->m, n = s->n, ld = s->ld;
+    double *xcol = (double *)malloc(sizeof(double) * (size_t)m);
+    s->counter = 0;
+    s->status = LPO_RUNNING;
+    while (s->counter < maxiters) {
+        s->counter += 1;
+        const double *rc = s->T + m * ld;
+        double mn = INFINITY;
+        int64_t k = -1; /* slot of the entering variable */
+        for (int64_t q = 0; q < n; ++q) {
+            if (rc[q] < mn) mn = rc[q];
+            if (s->pricing == 1) { /* opt-in Dantzig rule: most negative, smallest variable id on ties */
+                if (k < 0 || rc[q] < rc[k] || (rc[q] == rc[k] && slot_var[q] < slot_var[k])) k = q;
+            } else if (rc[q] < 0.0 && (k < 0 || slot_var[q] < slot_var[k])) k = q; /* :135-138 */
+        }
+        if (mn >= 0.0 || fabs(mn) <= ISCLOSE_ATOL) { /* :140-142 */
+            s->status = LPO_OPTIMAL;
+            break;
+        }
+        const int64_t j = slot_var[k];
+        for (int64_t i = 0; i <= m; ++i) s->d[i] = s->T[i * ld + k]; /* d = (B^-1 A)[:, j], d[m] = rc_j */
+        for (int64_t i = 0; i < m; ++i) xcol[i] = s->T[i * ld + n];
+        int64_t r;
+        double theta, dmax;
+        lpo_ratio_primal(xcol, s->d, m, s->f32_phase, &r, &theta, &dmax); /* :149-167 */
+        if (dmax <= 0) { s->status = LPO_PRIMAL_UNBOUNDED; break; }
+        const double dr = s->d[r];
+        for (int64_t i = 0; i <= m; ++i) s->e[i] = (-s->d[i]) / dr; /* :236-244 */
+        s->e[r] = 1.0 / dr;
+        const int64_t leaving = s->basis[r];
+        if (s->log && s->pivots < s->log_cap) {
+            s->log[3 * s->pivots + 0] = r;
+            s->log[3 * s->pivots + 1] = j;
+            s->log[3 * s->pivots + 2] = leaving;
+        }
+        s->pivots += 1;
+        s->basis[r] = j;
+        if (s->threads > 1) lpo_rank1_update_mt(s->T, m + 1, n + 1, ld, r, s->e, s->rowr);
+        else lpo_rank1_update(s->T, m + 1, n + 1, ld, r, s->e, s->rowr);
+        for (int64_t i = 0; i <= m; ++i) s->T[i * ld + k] = s->e[i]; /* the leaving variable's column */
+        slot_var[k] = leaving;
+        s->f32_phase = 0;
+    }
+    free(xcol);
+    return s->status;
+}
+
 /* Dual simplex on the carried tableau: DualNaiveSimplexSolver.solve (dual_solvers.py:82-108) with the rules of
  * :47-80 read off T -- leaving row = first x_B < 0 (column n), dual row = row r of T with basic columns forced to 0
  * (:39), reduced costs = row m, ratio test (-rc_j)/row_j over row_j < 0, first argmin; then the same pivot as

@@ -84,6 +84,8 @@ def lib():
         L.lpo_dual_row.restype = None
         L.lpo_tableau_solve.argtypes = [C.POINTER(_Tableau), C.c_int64]
         L.lpo_tableau_dual_solve.argtypes = [C.POINTER(_Tableau), C.c_int64]
+        L.lpo_tableau_solve_condensed.argtypes = [C.POINTER(_Tableau), _ip, C.c_int64]
+        L.lpo_tableau_solve_condensed.restype = C.c_int
         L.lpo_tableau_dual_solve.restype = C.c_int
         L.lpo_rank1_update.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _dp, _dp]
         L.lpo_rank1_update.restype = None
@@ -420,18 +422,36 @@ class OraclePrimalDual:
 class OracleTableau:
     """Tableau-form restatement (lpo_tableau_solve): carries T = B^-1 A, x_B and the reduced-cost row."""
 
-    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0, kind="primal"):
+    def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0, kind="primal",
+                 condensed=False):
         """kind = "dual": the dual simplex rules on the same tableau (lpo_tableau_dual_solve); the constructor then
-        checks dual instead of primal feasibility of the starting basis (dual_solvers.py:14-16)."""
+        checks dual instead of primal feasibility of the starting basis (dual_solvers.py:14-16).
+        condensed (primal only): carry the nonbasic columns only (lpo_tableau_solve_condensed), the layout the GPU
+        tableau solver uses by default; ``slot_var[k]`` is the variable in column slot k, column ``nslots`` is x_B."""
         self.kind = kind
+        self.condensed = bool(condensed)
+        assert not (condensed and kind != "primal")
         self.c, A32, self.b = preprocess(c, A, b)
         self.m, self.n = A32.shape
         m, n = self.m, self.n
         self.basis = np.array(basis).astype(np.int64)
-        self.ld = ld or (n + 1)
-        self.T = np.zeros((m + 1, self.ld))
+        self.ld = (n + 1) if self.condensed else (ld or (n + 1))  # condensed: the full tableau is only a stepping stone
         B = A32[:, self.basis]
-        if np.array_equal(B, np.eye(m, dtype=np.float32)):
+        slack_start = np.array_equal(B, np.eye(m, dtype=np.float32))
+        if self.condensed and slack_start and not np.any(self.c[self.basis]):
+            # B = I with zero basic costs: T = A, rc = c, x_B = b -- built directly in the condensed layout
+            nb = np.setdiff1d(np.arange(n), self.basis)
+            self.slot_var = nb.astype(np.int64)
+            self.nslots = k = nb.size
+            self.ld = ld or (k + 1)
+            self.T = np.zeros((m + 1, self.ld))
+            self.T[:m, :k] = A32[:, nb]
+            self.T[:m, k] = self.b
+            self.T[m, :k] = self.c[nb]
+            self._finish(m, n, log_cap, threads, pricing)
+            return
+        self.T = np.zeros((m + 1, self.ld))
+        if slack_start:
             if check and kind == "dual" and not np.all(self.c[self.basis] @ A32 <= self.c):
                 raise ValueError("BasisIsDualInfeasibleError")
             self.T[:m, :n] = A32
@@ -453,12 +473,25 @@ class OracleTableau:
             self.T[m, n] = -float(self.c[self.basis] @ bfs32)
         self.T[m, self.basis] = 0.0
         del A32
+        self.nslots = n
+        if self.condensed:
+            nb = np.setdiff1d(np.arange(n), self.basis)
+            self.slot_var = nb.astype(np.int64)
+            self.nslots = k = nb.size
+            self.ld = ld or (k + 1)
+            Tc = np.zeros((m + 1, self.ld))
+            Tc[:, :k] = self.T[:, nb]
+            Tc[:, k] = self.T[:, n]
+            self.T = Tc
+        self._finish(m, n, log_cap, threads, pricing)
+
+    def _finish(self, m, n, log_cap, threads, pricing):
         self.var_state = np.full(n, VS_LOWER, dtype=np.int32)
         self.var_state[self.basis] = VS_BASIC
         self.log = np.zeros((log_cap, 3), dtype=np.int64)
         self._d, self._e, self._rowr = np.zeros(m + 1), np.zeros(m + 1), np.zeros(self.ld)
         s = self.s = _Tableau()
-        s.m, s.n, s.ld = m, n, self.ld
+        s.m, s.n, s.ld = m, self.nslots, self.ld
         s.T, s.basis, s.var_state = _p(self.T, _dp), _p(self.basis, _ip), _p(self.var_state, _sp)
         s.f32_phase, s.pivots = 1, 0
         s.log, s.log_cap = _p(self.log, _ip), log_cap
@@ -466,9 +499,12 @@ class OracleTableau:
         s.pricing = int(pricing)
 
     def solve(self, maxiters=100):
-        f = lib().lpo_tableau_solve if self.kind == "primal" else lib().lpo_tableau_dual_solve
-        status = f(C.byref(self.s), int(maxiters))
-        xB = np.ascontiguousarray(self.T[: self.m, self.n])
+        if self.condensed:
+            status = lib().lpo_tableau_solve_condensed(C.byref(self.s), _p(self.slot_var, _ip), int(maxiters))
+        else:
+            f = lib().lpo_tableau_solve if self.kind == "primal" else lib().lpo_tableau_dual_solve
+            status = f(C.byref(self.s), int(maxiters))
+        xB = np.ascontiguousarray(self.T[: self.m, self.nslots])
         x, cost = expand_and_cost(xB, self.basis, self.c, self.n)
         p = int(self.s.pivots)
         return OracleResult(x=x, basis=self.basis.copy(), cost=cost, iters=int(self.s.counter), status=status,

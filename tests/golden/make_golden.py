@@ -250,10 +250,41 @@ def random_cases(large):
     for m_, n_, seed_ in ((1, 2, 0), (3, 5, 1), (5, 11, 2), (7, 9, 3), (33, 67, 4)):
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, m_, n_, seed_, 100000)
         add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, m_, n_, seed_, 100000)
+    # naive solvers at the batched kernels' size (float32 re-inversion per pivot)
+    add("gen_primal", "PrimalNaiveSimplexSolver", PN, gen.gen_primal, 64, 128, 0, 100000)
+    add("gen_dual", "DualNaiveSimplexSolver", DN, gen.gen_dual, 64, 128, 0, 100000)
     if large:
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 256, 512, 0, 100000, keep_x=False)
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 1000, 2000, 0, 400, keep_x=False)
         add("gen_primal", "PrimalRevisedSimplexSolver", PR, gen.gen_primal, 2000, 4000, 0, 60, keep_x=False)
+    return out
+
+
+def gen_columns(m, n, seed):
+    """bench.py's generator (float32 column blocks) in the (c, A, b, basis) order of the others."""
+    A, b, c, basis = gen.gen_primal_columns(m, n, seed, 0, n)
+    return c, A, b, basis
+
+
+def xlarge_cases():
+    """Prefixes on matrices large enough for the code paths that only engage on big inputs (staged pricing at A >= 64 MB,
+    the fused update + y pass, non-temporal streams, 4-KiB row alignment, multi-strip column gathers), and the bench's own
+    generator at three sizes.  The reference needs 1-3 s per pivot at m = 5000, so these are prefixes (maxiters hit)."""
+    out = []
+    PR, DR = primal_solvers.PrimalRevisedSimplexSolver, dual_solvers.DualRevisedSimplexSolver
+
+    def add(kind, solver, cls, g, m, n, seed, maxiters):
+        t0 = time.time()
+        c, A, b, basis = g(m, n, seed)
+        r = run_base(cls, c, A, b, basis, maxiters)
+        r.pop("x", None)
+        out.append(dict(gen=kind, solver=solver, m=m, n=n, seed=seed, maxiters=maxiters, ref=r))
+        print(f"  {solver} {kind} m={m} seed={seed}: {len(r['pivots'])} pivots, {time.time() - t0:.1f}s", flush=True)
+
+    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 64, 128, 0, 100000)
+    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 1000, 2000, 0, 400)
+    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 5000, 10000, 0, 40)
+    add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, 5000, 10000, 0, 40)
     return out
 
 
@@ -277,7 +308,7 @@ def degenerate_cases():
 def bounded_cases():
     out = []
     for m in (16, 64, 128, 170):
-        for seed in range(2 if m < 170 else 1):
+        for seed in range(2):
             t0 = time.time()
             c, A, b, lb, ub, basis, lbn, ubn = gen.gen_box(m, 2 * m, seed)
             r = run_bounded(c, A, b, lb, ub, basis, lbn, ubn, 100000)
@@ -288,7 +319,7 @@ def bounded_cases():
 
 def primal_dual_cases():
     out = []
-    for m in (4, 8, 16, 32):
+    for m in (4, 8, 16, 32, 64):  # 64: the size bench.py --workload config5 times
         for seed in range(2):
             t0 = time.time()
             c, A, b, _ = gen.gen_dual(m, 2 * m, seed)
@@ -306,6 +337,7 @@ def primal_dual_cases():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also m=256 full solve and m=1000/2000 prefixes (minutes)")
+    ap.add_argument("--xlarge", action="store_true", help="also the m=5000 prefixes and the bench generator's goldens (minutes)")
     ap.add_argument("--only", default=None, help="write only this fixture file (e.g. random.json)")
     args = ap.parse_args()
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],
@@ -327,6 +359,8 @@ def main():
     dump("degenerate.json", degenerate_cases)
     if args.large:
         dump("random_large.json", lambda: random_cases(True)[-3:])
+    if args.xlarge:
+        dump("random_xlarge.json", xlarge_cases)
 
 
 if __name__ == "__main__":

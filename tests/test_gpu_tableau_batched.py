@@ -14,13 +14,17 @@ def logged(cls, cap):
     return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
 
 
+@pytest.mark.parametrize("chain", ["one-launch", "three-launch"])
 @pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
 @pytest.mark.parametrize("cs", PRIMAL, ids=case_id)
-def test_tableau_matches_reference(cs, condensed):
-    """Both layouts of the carried tableau -- nonbasic columns only (the default) and every column -- against the
-    reference's golden pivot sequences and results."""
+def test_tableau_matches_reference(cs, condensed, chain, monkeypatch):
+    """Both layouts of the carried tableau -- nonbasic columns only (the default) and every column -- and both launch
+    chains -- one launch per pivot on two alternating buffers (default at these sizes) and the in-place three-kernel
+    chain of the large configurations -- against the reference's golden pivot sequences and results."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
 
+    if chain == "three-launch":
+        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
     ref = cs["ref"]
     c, A, b, basis = problem_of(cs)
     s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis, condensed=condensed)
@@ -32,19 +36,27 @@ def test_tableau_matches_reference(cs, condensed):
     assert_close(res.cost, ref["cost"], "cost")
 
 
-def test_tableau_bit_exact_vs_oracle():
+@pytest.mark.parametrize("chain", ["one-launch", "three-launch"])
+def test_tableau_bit_exact_vs_oracle(chain, monkeypatch):
     """Elementwise path (no reductions over floating-point sums): the carried tableau must be bit-identical."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
     from oracle import oracle as O
 
+    if chain == "three-launch":
+        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
     c, A, b, basis = gen.gen_primal(96, 200, 11)
     s = PrimalTableauSimplexSolver(c, A, b, basis, condensed=False)
     sc = PrimalTableauSimplexSolver(c, A, b, basis, condensed=True)
+    assert (s._engine.T_alt is not None) and (sc._engine.T_alt is not None)
     o = O.OracleTableau(c, A, b, basis)
-    for k in (1, 7, 40):
+    oc = O.OracleTableau(c, A, b, basis, condensed=True)
+    for k in (1, 7, 40):  # 1 and 7: the call ends on odd parity, the state must come back to T
         s.solve(k)
         sc.solve(k)
         o.solve(k)
+        oc.solve(k)
+        assert np.array_equal(sc._engine.T.cpu().numpy()[:, :105], oc.T[:, :105])
+        assert np.array_equal(sc._engine.slot_var.cpu().numpy(), oc.slot_var)
         T = s._engine.T.cpu().numpy()
         assert np.array_equal(T[:, :201], o.T[:, :201])
         # condensed form: slot k carries variable slot_var[k]; the slots and the basis partition the variables
@@ -54,6 +66,54 @@ def test_tableau_bit_exact_vs_oracle():
         assert np.array_equal(var_slot[slot_var], np.arange(eng.n)) and np.all(var_slot[sc.basis] == -1)
         assert np.array_equal(Tc[:, :eng.n], o.T[:, slot_var])
         assert np.array_equal(Tc[:, eng.n], o.T[:, 200])
+
+
+@pytest.mark.parametrize("rows", ["0", "1", "4"])
+@pytest.mark.parametrize("m,n,condensed", [(300, 700, True), (300, 700, False), (530, 1061, True), (64, 1200, True),
+                                           (700, 760, True)])
+def test_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, monkeypatch):
+    """The single-launch chain with several lookahead workgroups (m + 1 > 256), several column strips and every update
+    tile height, in calls of odd and even length (ping-pong parity, hipGraph replays from 32 iterations on): pivot log,
+    tableau, basis and column maps bit-identical to the oracle's loop on the same layout."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    monkeypatch.setenv("LPX_FUSED_ROWS", rows)
+    c, A, b, basis = gen.gen_primal(m, n, 5)
+    s = logged(PrimalTableauSimplexSolver, 512)(c, A, b, basis, condensed=condensed)
+    assert s._engine.T_alt is not None
+    o = O.OracleTableau(c, A, b, basis, condensed=condensed, log_cap=512)
+    done = 0
+    for k in (1, 2, 5, 64, 33):
+        res = s.solve(k)
+        r = o.solve(k)
+        done += k
+        assert s.pivot_log().tolist() == o.log[:done].tolist()
+        w = o.nslots + 1
+        T = s._engine.T.cpu().numpy()
+        assert np.array_equal(T[:, :w], o.T[:, :w])
+        assert res.basis.tolist() == r.basis.tolist() and res.iters == r.iters and np.array_equal(res.x, r.x)
+        assert_close(res.cost, r.cost, "cost")  # dot(c, x): the device sums it as a tree, the oracle in index order
+        if condensed:
+            assert np.array_equal(s._engine.slot_var.cpu().numpy(), o.slot_var)
+
+
+def test_one_launch_chain_runs_to_the_reference_optimum_and_stays_there():
+    """Full solve through the single-launch chain (graph replays, termination inside a replayed chunk), then a second
+    solve() on the optimal state: iters == 1, nothing moves (tests/test_primal_base_solvers.py:24-34's re-entrancy)."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = gen.gen_primal(128, 256, 0)
+    s = logged(PrimalTableauSimplexSolver, 1024)(c, A, b, basis)
+    res = s.solve(100000)
+    want = O.OracleTableau(c, A, b, basis, condensed=True, log_cap=1024).solve(100000)
+    assert res.optimum and res.iters == want.iters and s.pivot_log().tolist() == want.log.tolist()
+    assert np.array_equal(res.x, want.x)
+    assert_close(res.cost, want.cost, "cost")
+    T0 = s._engine.T.clone()
+    again = s.solve(100)
+    assert again.optimum and again.iters == 1 and bool((s._engine.T == T0).all())
 
 
 def test_tableau_unbounded_and_infeasible_start():
