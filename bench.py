@@ -36,6 +36,11 @@ def parse():
     ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "dual10k", "config5"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--m", type=int, default=None, help="tableau workloads: rows (default: the config's)")
+    ap.add_argument("--n", type=int, default=None, help="tableau workloads: columns")
+    ap.add_argument("--headline-only", action="store_true", help="default workload: skip the nested batch / tableau1k legs")
+    ap.add_argument("--batch-scaling", default="strong", choices=["strong", "weak"],
+                    help="batch workload at N > 1: 4096 LPs in total (BASELINE config 3) or 4096 per GPU")
     return ap.parse_args()
 
 
@@ -64,8 +69,6 @@ def main():
     import torch.distributed as dist
 
     import linprog_amd  # noqa: F401
-    from linprog_amd import _lib, problems
-    from linprog_amd.tableau import PrimalTableauSimplexSolver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,17 +96,53 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
+    def finish(out):
+        if rank == 0 and out is not None:
+            emit(out)
+        if group is not None:
+            dist.barrier()  # rank 0's oracle checks are done: nobody tears the communicator down under a busy peer
+            dist.destroy_process_group()
+
     if args.workload == "batch":
-        return bench_batch(args, rank, world, group)
+        return finish(bench_batch(args, rank, world, group, args.steps, args.warmup))
     if args.workload.startswith("revised"):
         return bench_revised(args)
     if args.workload == "config5":
         return bench_config5(args)
     if args.workload == "dual10k":
         return bench_dual(args)
+    if args.workload == "tableau1k":
+        return finish(bench_tableau(args, rank, world, group, args.m or 1000, args.n or 2000, args.steps, args.warmup))
 
-    m, n = (20000, 40000) if args.workload == "tableau" else (1000, 2000)
-    K, W = args.steps, args.warmup
+    # default: the headline leg (20000 x 40000 tableau) and, in the same JSON line, the metric's other legs as nested
+    # records with their own roofline / cpu_baseline: "batch" = config 3 (4096 LPs of 64 x 128, sharded over the ranks),
+    # "tableau1k" = config 2 (1000 x 2000, one GPU).  --headline-only skips the nested legs.
+    out = bench_tableau(args, rank, world, group, args.m or 20000, args.n or 40000, args.steps, args.warmup)
+    if not args.headline_only and not (args.m or args.n):
+        import torch
+
+        torch.cuda.empty_cache()
+        sub = bench_batch(args, rank, world, group, 40, 5)
+        if rank == 0:
+            out["batch"] = sub
+        if world == 1:
+            sub = bench_tableau(args, rank, world, None, 1000, 2000, 4000, 100)
+            if rank == 0:
+                out["tableau1k"] = sub
+    finish(out)
+
+
+def bench_tableau(args, rank, world, group, m, n, K, W):
+    """One leg: K timed pivots of the tableau loop on gen_primal_columns(m, n).  Returns the record (every rank)."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from linprog_amd import _lib, problems
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    backend = os.environ.get("LPX_BENCH_BACKEND", "nccl")
     # the tableau carries the nonbasic columns only (condensed form): with the slack starting basis these are the n - m
     # structural columns, partitioned evenly over the ranks; LPX_TABLEAU_CONDENSED=0: every column, n / world per rank
     condensed = PrimalTableauSimplexSolver.CONDENSED
@@ -117,18 +156,17 @@ def main():
     lib = _lib.load()
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
+    one_launch = eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
 
     def barrier():
         if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    import ctypes as C
-
-    # K1 is timed with HIP events on the launch stream.  For the headline 20k x 40k workload they are recorded
-    # inside the timed region.  The 1k x 2k workload is launch-bound and liblpx replays it as hipGraphs (event
-    # records cannot ride along), so there K1 is timed in a separate eager pass of the same pivots afterwards.
-    events_in_timed = args.workload == "tableau" or group is not None
+    # The update kernel is timed with HIP events on the launch stream.  At HBM-bound sizes they are recorded inside the
+    # timed region.  Launch-bound sizes are replayed as hipGraphs (event records cannot ride along), so there the kernel
+    # is timed in a separate eager pass of further pivots afterwards.
+    events_in_timed = m >= 10000 or group is not None
     _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, torch.cuda.current_stream().cuda_stream))
     eng.enqueue(W)
     barrier()
@@ -157,24 +195,25 @@ def main():
     if pivots_done != W + K + extra or ctrl.status != _lib.RUNNING:
         sys.exit(f"bench invalid: {pivots_done} pivots done of {W + K + extra}, status {ctrl.status}")
 
-    # roofline of K1 on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
+    # roofline of the update kernel on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
     n_loc = j1 - j0
     bytes_per_launch = 16.0 * (m + 1) * (n_loc + 1)
     k1_avg_s = (k1_ms.value / 1e3) / max(1, k1_n.value)
     achieved = bytes_per_launch / k1_avg_s / 1e9
-    traffic = None
+    traffic = traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-    if os.path.exists(tpath) and args.workload == "tableau" and world == 1:
+    if os.path.exists(tpath) and m == 20000 and n == 40000 and world == 1:
         try:
             rec = json.load(open(tpath))
             # the PMC figure belongs to one layout: use it only for the layout it was measured on
             if 0.9 * bytes_per_launch <= rec.get("hbm_bytes_per_launch", 0) <= 1.2 * bytes_per_launch:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = (f"NOT measured in this run: read from profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                               f"WRITE_SIZE passes of this command, tag {rec.get('tag')}: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)")
         except Exception:
             traffic = None
     out = {
-        "metric": "simplex pivots/sec (20000x40000 fp64 tableau)" if args.workload == "tableau"
-        else "simplex pivots/sec (1000x2000 fp64 tableau)",
+        "metric": f"simplex pivots/sec ({m}x{n} fp64 tableau)",
         "value": K / dt,
         "unit": "pivots/s",
         "n_gpus": world,
@@ -191,44 +230,50 @@ def main():
                    "m": m, "n": n,
                    "form": "condensed tableau: (m+1) x (n-m+1), the nonbasic columns and x_B (basic columns are unit "
                            "vectors no pivot changes)" if condensed else "full tableau: (m+1) x (n+1)",
+                   "launches_per_pivot": 1 if one_launch else 3,
                    "partition": f"columns/{world}",
                    "setup_s": round(t_setup, 2)},
-        "roofline": {"bound": "hbm", "kernel": "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1_avg_s * 1e3, "launches": k1_n.value,
+        "roofline": {"bound": "hbm", "kernel": "k_t_fused (update + next pivot's pricing / column / ratio test, two buffers)"
+                     if one_launch else "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "bytes_per_launch": bytes_per_launch, "layout_bytes_full": 16.0 * (m + 1) * (n + 1),
+                     "avg_launch_ms": k1_avg_s * 1e3, "launches": k1_n.value,
                      "k1_timing": "HIP events in the timed region" if events_in_timed
                      else "HIP events in a separate eager pass (timed region replays hipGraphs)",
                      "whole_pivot_GBs": 16.0 * (m + 1) * (ncarry + 1) * K / dt / 1e9},
     }
+    if not events_in_timed:
+        out["roofline"]["note"] = ("launch/latency-bound size (the tableau is " + f"{8e-6 * (m + 1) * (n_loc + 1):.0f}"
+                                   " MB: Infinity-Cache resident): the fraction of HBM peak is reported, not claimed as a "
+                                   "bandwidth result")
     if rank == 0 and world == 1:
         A_full = A_cols if not condensed else problems.gen_primal_columns(m, n, args.seed, 0, n)[0]
-        out["cpu_baseline"] = cpu_baseline(args, m, n, A_full, b, c, basis, solver)
+        out["cpu_baseline"] = cpu_baseline(args, m, n, A_full, b, c, basis, solver, condensed)
     elif rank == 0:
         # N>1: rank 0 regenerates the whole matrix and checks the partitioned run's first pivots against the oracle
         full = problems.gen_primal_columns(m, n, args.seed, 0, n)
         kc = args.cpu_pivots if args.cpu_pivots is not None else (12 if m >= 10000 else 400)
-        chk = cpu_baseline(args, m, n, full[0], full[1], full[2], full[3], solver, kc=kc)
+        chk = cpu_baseline(args, m, n, full[0], full[1], full[2], full[3], solver, condensed, kc=kc)
         out["parity"] = None if chk is None else chk["parity"]
-    if rank == 0:
-        emit(out)
-    if group is not None:
-        dist.barrier()  # rank 0's oracle check is done: nobody tears the communicator down under a busy peer
-        dist.destroy_process_group()
+    del solver, eng
+    return out
 
 
-def cpu_baseline(args, m, n, A, b, c, basis, solver, kc=None):
-    """Oracle tableau loop (C, OpenMP) on the host cores, bounded sample; also the parity gate of the timed run."""
+def cpu_baseline(args, m, n, A, b, c, basis, solver, condensed, kc=None):
+    """Oracle tableau loop (C, OpenMP) on the host cores IN THE LAYOUT THE GPU RAN (condensed: nonbasic columns only, so
+    both sides move the same bytes per pivot), bounded sample; also the parity gate of the timed run."""
     from oracle import oracle as O
 
     cores = min(16, os.cpu_count() or 1)
     if kc is None:
         kc = args.cpu_pivots
     if kc is None:
-        kc = 200 if m >= 10000 else 2000  # ~10 s of host work at the headline size
+        kc = 300 if m >= 10000 else 4000  # ~10 s of host work at the headline size
     if kc <= 0:
         return None
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    o = O.OracleTableau(c, A, b, basis, log_cap=kc + 1, threads=cores, ld=n + 1 + ((n + 1) % 2))
+    ncarry = n - m if condensed else n
+    o = O.OracleTableau(c, A, b, basis, log_cap=kc + 1, threads=cores, ld=ncarry + 1 + ((ncarry + 1) % 2), condensed=condensed)
     t0 = time.perf_counter()
     r = o.solve(kc)
     dt = time.perf_counter() - t0
@@ -239,7 +284,8 @@ def cpu_baseline(args, m, n, A, b, c, basis, solver, kc=None):
         sys.exit("bench invalid: GPU pivot sequence differs from the oracle's on the same workload")
     done = len(r.log)
     return {"value": done / dt, "unit": "pivots/s", "cores": cores, "kind": "port",
-            "sample": f"first {done} pivots of the same workload, oracle tableau loop (C + OpenMP rank-1 update)",
+            "layout": f"{'condensed' if condensed else 'full'} tableau, {m + 1} x {ncarry + 1} (the layout the GPU ran)",
+            "sample": f"first {done} pivots of the same workload, oracle tableau loop (C + OpenMP rank-1 update, {cores} threads)",
             "parity": f"GPU and oracle (row, entering, leaving) sequences identical on the first {both} pivots"}
 
 
@@ -444,26 +490,40 @@ def bench_config5(args):
     emit(out)
 
 
-def bench_batch(args, rank, world, group):
-    """Config 3: 4096 x gen_primal(64, 128, seed) full solves, sharded by LP index (weak: per-GPU count fixed)."""
+FP64_FMA_PEAK = 78.6e12 / 2  # MI355X_MICROARCH.md: 78.6 TFLOP/s vector fp64 = 39.3 T fma/s
+
+
+def bench_batch(args, rank, world, group, K, W):
+    """Config 3: 4096 x gen_primal(64, 128, seed) full solves.  N > 1 ("strong", BASELINE config 3): the FIXED batch of
+    4096 LPs is split over the ranks by LP index (ShardedBatch), no collective during the solve, one all-gather of the
+    results per step inside the timed region.  --batch-scaling weak: 4096 LPs per GPU, no gather.  Returns the record."""
     import torch
     import torch.distributed as dist
 
     from linprog_amd import problems
-    from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver
+    from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver, ResultGather, shard
 
     # carried state per LP: the condensed tableau in registers (default) or B^-1 in LDS (LPX_BATCH_FORM=revised)
     tableau_form = os.environ.get("LPX_BATCH_FORM", "tableau") != "revised"
     Batched = BatchedTableauSolver if tableau_form else BatchedPrimalSolver
-    per_gpu = 4096
-    seeds = range(rank * per_gpu, (rank + 1) * per_gpu)
-    probs = [problems.gen_primal(64, 128, s) for s in seeds]
+    total = 4096
+    weak = args.batch_scaling == "weak" and world > 1
+    if weak:
+        lo, hi = rank * total, (rank + 1) * total
+    else:
+        lo, hi = shard(total, rank, world)
+    count = hi - lo
+    m, n = 64, 128
+    probs = [problems.gen_primal(m, n, s) for s in range(lo, hi)]
+    args4 = [np.stack([p[k] for p in probs]) for k in range(4)]
     # Two solver objects on two streams, alternating: consecutive batches overlap, so the tail of one launch (the last
     # long LPs running alone on a mostly idle chip) is covered by the head of the next.  Every step is still one full
-    # pass over one batch of 4096 LPs with its own inputs and outputs.
-    args4 = [np.stack([p[k] for p in probs]) for k in range(4)]
+    # pass over one batch with its own inputs and outputs.  The single-stream figure (no overlap) is measured as well.
     solvers = [Batched(*args4) for _ in range(2)]
     streams = [torch.cuda.Stream() for _ in range(2)]
+    gathers = None
+    if group is not None and not weak:
+        gathers = [ResultGather(group, total, m, n, "cuda") for _ in range(2)]
     solver = solvers[0]
     basis0 = solver.basis.clone()
     torch.cuda.synchronize()
@@ -473,54 +533,85 @@ def bench_batch(args, rank, world, group):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(count):
-        for i in range(count):
-            with torch.cuda.stream(streams[i & 1]):
-                solvers[i & 1].basis.copy_(basis0)
-                solvers[i & 1].enqueue(100000)
+    def run(cnt, two_streams):
+        for i in range(cnt):
+            q = (i & 1) if two_streams else 0
+            with torch.cuda.stream(streams[q]):
+                s = solvers[q]
+                s.basis.copy_(basis0)
+                s.enqueue(100000)
+                if gathers is not None:  # the one collective: every rank ends the step holding all 4096 results
+                    gathers[q].pack(s.x, s.cost, s.basis, s.status, s.iters, s.pivots)
+                    gathers[q].all_gather()
 
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(two_streams):
+        run(W, two_streams)
+        barrier()
+        t0 = time.perf_counter()
+        run(K, two_streams)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt1 = timed(False)
+    dt = timed(True)
+    piv_t = torch.tensor([float(solver.pivots.sum().item())], dtype=torch.float64, device="cuda")
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    piv = int(solver.pivots.sum().item())
+        if dist.get_backend() != "nccl":
+            piv_t = piv_t.cpu()
+        dist.all_reduce(piv_t)
+    piv = int(piv_t.item())  # pivots of one step over all ranks
     ok = bool((solver.status == 1).all().item())
-    m, n = 64, 128
-    # the "algorithmic bytes" of a pivot by the tableau formula, 16 (m+1)(n+1) B; the state is LDS-resident
-    # by design, so this rate is not HBM traffic and may exceed the HBM peak.  `traffic` is the honest HBM figure: one load
-    # of (A, b, c, basis) and one store of (x, basis, cost, status, iters, pivots) per LP and launch.
-    ncarry = n - m if tableau_form else n  # the tableau kernel carries the nonbasic columns only
-    alg = 16.0 * (m + 1) * (ncarry + 1) * piv * world * args.steps / dt / 1e9
-    hbm_per_launch = per_gpu * (4.0 * (m * n + m + n) + 8 * m + 8.0 * n + 8 * m + 8 + 4 + 8 + 8)
-    out = {"metric": "batched LPs solved/sec (m=64 n=128)", "value": per_gpu * world * args.steps / dt, "unit": "LPs/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "4096 x gen_primal(64,128,seed) per GPU, full solves (maxiters 100000), one wave per LP; consecutive batches "
-                                  "alternate between two streams",
+    lps = total * world if weak else total
+    # Bounds.  The solver state lives in registers, so HBM sees one load of (A, b, c, basis) and one store of
+    # (x, basis, cost, status, iters, pivots) per LP and launch: `achieved` is that true traffic over the launch time -- a
+    # tiny fraction of the HBM peak, which is the point.  The kernel is bound by fp64 VALU issue: `valu` prices the fma
+    # count of the rank-1 updates, m x (k + 1) per pivot, against the vector fp64 peak.  SURVEY.md 8(d)'s tableau-formula
+    # rate 16 (m+1)(n_carried+1) B per pivot is served from registers and is given as information only.
+    ncarry = n - m if tableau_form else n
+    hbm_per_launch = count * (4.0 * (m * n + m + n) + 8 * m + 8.0 * n + 8 * m + 8 + 4 + 8 + 8)
+    per_launch_s = dt / K
+    achieved = hbm_per_launch / per_launch_s / 1e9
+    fma_rate = piv * float(m) * (ncarry + 1) * K / dt
+    out = {"metric": "batched LPs solved/sec (m=64 n=128)", "value": lps * K / dt, "unit": "LPs/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+           "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": (f"{total} x gen_primal(64,128,seed) per GPU" if weak else
+                                   f"{total} x gen_primal(64,128,seed) in total, split over the ranks by LP index, one "
+                                   f"all-gather of the results per step") +
+                                  ", full solves (maxiters 100000), one wave per LP; `value`: consecutive batches alternate "
+                                  "between two streams; `single_stream`: back to back on one stream, no overlap",
                       "form": "condensed tableau in registers (lpx_batched_tableau_solve)" if tableau_form
                       else "revised form, B^-1 in LDS (lpx_batched_primal_solve)",
-                      "pivots_per_step_per_gpu": piv, "all_optimal": ok,
-                      "pivots_per_s": piv * world * args.steps / dt},
-           "roofline": {"bound": "hbm", "kernel": "k_batched_tab" if tableau_form else "k_batched_wave", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / HBM_PEAK_GBS, "traffic": hbm_per_launch,
-                        "note": "register/LDS-resident solver state: 'achieved' is the tableau-formula byte count of SURVEY 8(d) for the "
-                                "carried columns, served from registers and LDS, not HBM; 'traffic' is the HBM bytes one launch "
-                                "really moves"}}
+                      "lps_per_gpu": count, "pivots_per_step": piv, "all_optimal": ok,
+                      "pivots_per_s": piv * K / dt},
+           "single_stream": {"value": lps * K / dt1, "unit": "LPs/s", "ms_per_step": dt1 / K * 1e3,
+                             "pivots_per_s": piv * K / dt1},
+           "roofline": {"bound": "hbm", "kernel": "k_batched_tab" if tableau_form else "k_batched_wave",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": hbm_per_launch,
+                        "traffic_source": "computed: bytes of the kernel's inputs and outputs per launch (this rank)",
+                        "valu": {"fma_per_s": fma_rate, "peak_fma_per_s": FP64_FMA_PEAK * world,
+                                 "frac": fma_rate / (FP64_FMA_PEAK * world),
+                                 "note": "fma of the rank-1 updates, m x (carried columns + 1) per pivot, against the vector "
+                                         "fp64 peak: the bound that matters for a register-resident solver"},
+                        "tableau_formula_GBs": 16.0 * (m + 1) * (ncarry + 1) * piv * K / dt / 1e9,
+                        "note": "register-resident solver state: HBM traffic is inputs + outputs only, so `frac` is small "
+                                "by design; see `valu`"}}
     if rank == 0 and (args.cpu_pivots is None or args.cpu_pivots > 0):
-        # the whole rank-0 batch through the oracle, one LP per core: CPU baseline and bit-exact parity gate in one
+        # rank 0's LPs through the oracle, one LP per core: CPU baseline and bit-exact parity gate in one
         from oracle import oracle as O
 
         cores = min(16, os.cpu_count() or 1)
         c, A, b, basis = [np.stack([p[k] for p in probs]) for k in range(4)]
         O.primal_solve_batch(c[:64], A[:64], b[:64], basis[:64], 100000, threads=cores)  # thread pool, page faults
         reps, dc = 0, 0.0
-        while dc < 5.0 and reps < 50:
+        while dc < 4.0 and reps < 50:
             t1 = time.perf_counter()
             r = O.primal_solve_batch(c, A, b, basis, 100000, threads=cores)
             dc += time.perf_counter() - t1
@@ -528,32 +619,35 @@ def bench_batch(args, rank, world, group):
         res = solver.results()
         if tableau_form:
             # same pivots as the revised-form oracle on every LP (basis, iteration count), x and cost to 1e-9; and bit for
-            # bit the oracle's TABLEAU loop, LP by LP (single thread, Python loop: a sample of 512)
+            # bit the oracle's TABLEAU loop, LP by LP (single thread, Python loop: a sample)
             same = (np.array_equal(res["basis"], r["basis"]) and np.array_equal(res["iters"], r["iters"])
                     and np.allclose(res["x"], r["x"], rtol=1e-9, atol=1e-9) and np.allclose(res["cost"], r["cost"], rtol=1e-9, atol=1e-9))
-            for i in range(0, per_gpu, per_gpu // 512):
+            step = max(1, count // 256)
+            for i in range(0, count, step):
                 o = O.OracleTableau(*probs[i], log_cap=4).solve(100000)
                 same = same and np.array_equal(res["x"][i], o.x) and res["cost"][i] == o.cost and res["iters"][i] == o.iters
-            how = (f"basis and iters of all {per_gpu} LPs identical to the revised-form oracle's, x and cost within 1e-9; x, cost and "
-                   f"iters of 512 sampled LPs bit-identical to the oracle's tableau loop")
+            how = (f"basis and iters of all {count} LPs of rank 0 identical to the revised-form oracle's, x and cost within 1e-9; "
+                   f"x, cost and iters of {len(range(0, count, step))} sampled LPs bit-identical to the oracle's tableau loop")
         else:
             same = (np.array_equal(res["x"], r["x"]) and np.array_equal(res["cost"], r["cost"])
                     and np.array_equal(res["basis"], r["basis"]) and np.array_equal(res["iters"], r["iters"]))
-            how = f"x, cost, basis and iters of all {per_gpu} LPs bit-identical to the GPU's"
+            how = f"x, cost, basis and iters of all {count} LPs of rank 0 bit-identical to the GPU's"
+        if same and gathers is not None:
+            # the gathered batch: rank 0's rows are its own results, every row is an optimal solve
+            g = gathers[0].unpack()
+            same = bool(np.array_equal(g["x"][lo:hi], res["x"]) and (g["status"] == 1).all() and g["x"].shape[0] == total)
+            how += f"; gathered batch: {total} rows, all optimal, rank 0's rows equal its own results"
         if not same:
             sys.exit("bench invalid: batched GPU results differ from the oracle's on the same batch")
         if world == 1:
-            out["cpu_baseline"] = {"value": per_gpu * reps / dc, "unit": "LPs/s", "cores": cores, "kind": "port",
-                                   "sample": f"the same {per_gpu} LPs x {reps} passes, oracle revised loop (C), one LP per "
+            out["cpu_baseline"] = {"value": count * reps / dc, "unit": "LPs/s", "cores": cores, "kind": "port",
+                                   "sample": f"the same {count} LPs x {reps} passes, oracle revised loop (C), one LP per "
                                              f"OpenMP thread",
                                    "parity": how}
         else:
             out["parity"] = "rank 0: " + how
-    if rank == 0:
-        emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    del solvers, gathers
+    return out
 
 
 if __name__ == "__main__":

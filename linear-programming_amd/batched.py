@@ -66,7 +66,10 @@ class BatchedPrimalSolver:
         else:
             inv = np.linalg.inv(Bmat)
             self.Binv0 = to_device(np.ascontiguousarray(inv.astype(np.float32)))
-            bfs = np.einsum("bij,bj->bi", inv, b32)
+            # the reference's own expression per LP (primal_solvers.py:38, a BLAS gemv): an einsum over the batch may
+            # round a degenerate x_B (about 0) to the other sign
+            bfs = np.stack([inv[i] @ b32[i] for i in range(self.B)])
+            self._inv32, self._bfs32 = inv, bfs  # reused by BatchedTableauSolver's starting tableau
         if self._DUAL:
             inv = np.broadcast_to(eye, Bmat.shape) if self.Binv0 is None else inv
             cB = np.take_along_axis(c32, basis, axis=1)
@@ -129,9 +132,13 @@ class BatchedDualSolver(BatchedPrimalSolver):
 class BatchedTableauSolver(BatchedPrimalSolver):
     """The same per-LP semantics with the condensed tableau as carried state (``lpx_batched_tableau_solve``): one rank-1
     update per pivot instead of three chains of m dependent fmas, the tableau in registers.  Bit-identical to the oracle's
-    tableau loop; the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64.  From the slack basis with
-    zero basic costs (``from_inequalities``, every synthetic config) the kernel reads A itself; from any other primal
-    feasible basis the float32 starting tableau is formed on the host as the reference's constructor would."""
+    tableau loop; from the slack basis with zero basic costs (``from_inequalities``, every synthetic config) the kernel
+    reads A itself and takes the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64.
+    From any other primal feasible basis the float32 starting tableau ``inv32 @ A`` is formed on the host as the
+    reference's constructor state and CARRIED for the whole solve, whereas the reference recomputes ``inv64 @ A`` in
+    float64 from its second pivot on: x and cost then agree with the reference and with the revised-form kernel to
+    float32 accuracy only (about 1e-5 relative), and a reduced cost within ~1e-7 of zero may pick another pivot.  Use
+    ``BatchedPrimalSolver`` where 1e-9 is needed from a general start (``solve_many`` does)."""
 
     def __init__(self, c, A, b, basis, log_cap=0):
         super().__init__(c, A, b, basis, log_cap=log_cap)  # preprocessing, feasibility check (primal_solvers.py:41-53)
@@ -152,14 +159,14 @@ class BatchedTableauSolver(BatchedPrimalSolver):
             xb0 = np.empty((self.B, self.m), dtype=np.float32)
             var0 = np.empty((self.B, k), dtype=np.int64)
             for i in range(self.B):
-                inv32 = np.linalg.inv(A32[i][:, basis[i]])
+                inv32 = self._inv32[i] if self.Binv0 is not None else np.eye(self.m, dtype=np.float32)
                 nb = np.setdiff1d(np.arange(self.n), basis[i])
                 if nb.size != k:
                     raise ValueError("a basis needs m distinct columns")
                 var0[i] = nb
                 T0[i] = (inv32 @ A32[i])[:, nb]
                 rc0[i] = (c32[i] - c32[i][basis[i]] @ inv32 @ A32[i])[nb]
-                xb0[i] = inv32 @ b32[i]
+                xb0[i] = self._bfs32[i] if self.Binv0 is not None else b32[i]  # the value the feasibility check saw
             self.start = tuple(to_device(np.ascontiguousarray(v)) for v in (T0, rc0, xb0, var0))
             self.basis0 = self.basis.clone()
 
@@ -214,8 +221,11 @@ class BatchedDualTableauSolver(BatchedDualSolver):
 def solve_many(problems, maxiters=100, form="revised"):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
     launches of different shapes run on separate streams, results come back in input order.  ``form="tableau"``: groups
-    that qualify (slack start, m <= 64, n - m <= 64) go through the faster condensed-tableau kernel, whose x and cost
-    agree with the revised form's to 1e-9 (same pivots) rather than bit for bit."""
+    that qualify (SLACK start with zero basic costs, m <= 64, n - m <= 64) go through the faster condensed-tableau kernel,
+    whose x and cost agree with the revised form's to 1e-9 (same pivots) rather than bit for bit; every other group --
+    any non-slack starting basis included -- takes the revised-form kernels in both modes (bit-identical to the oracle's
+    revised loop from the same float32 starting inverse; the tableau kernel would carry a float32 starting tableau for
+    the whole solve, see ``BatchedTableauSolver``)."""
     torch = torch_cuda()
     groups = {}
     for idx, (c, A, b, basis) in enumerate(problems):
@@ -231,7 +241,9 @@ def solve_many(problems, maxiters=100, form="revised"):
             if form == "tableau":
                 try:
                     s = BatchedTableauSolver(*args)
-                except ValueError:  # not a slack start or too large for a wave: the revised-form kernels take it
+                    if s.start is not None:  # general start: that kernel carries a float32 tableau (1e-5, not 1e-9)
+                        s = None
+                except ValueError:  # too large for a wave: the revised-form kernels take it
                     s = None
             if s is None:
                 s = BatchedPrimalSolver(*args)
@@ -250,3 +262,104 @@ def solve_many(problems, maxiters=100, form="revised"):
 def shard(count, rank, world):
     """Contiguous LP index range of `rank` (independent units: no data-path collective)."""
     return count * rank // world, count * (rank + 1) // world
+
+
+class ResultGather:
+    """The one collective of a sharded batch: after the solve every rank contributes its slice of
+    the results and receives the whole batch.  A result row is ``n + m + 4`` 8-byte words per LP -- x (n float64), cost,
+    basis (m int64), status, iters, pivots -- packed into ONE int64 buffer so that a single ``all_gather_into_tensor``
+    moves everything.  Slices are padded to the largest shard (``all_gather_into_tensor`` wants equal pieces).
+    Backend "nccl" (= RCCL over xGMI) gathers device buffers in stream order; "gloo" (CPU rehearsal, tests) stages
+    through the host."""
+
+    def __init__(self, group, total, m, n, device):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.total, self.m, self.n = int(total), int(m), int(n)
+        self.words = self.n + self.m + 4
+        self.per = max(shard(self.total, g, self.world)[1] - shard(self.total, g, self.world)[0] for g in range(self.world))
+        self.send = torch.zeros((self.per, self.words), dtype=torch.int64, device=device)
+        self.recv = torch.zeros((self.world * self.per, self.words), dtype=torch.int64, device=device)
+        self.staged = dist.get_backend(group) == "gloo" and self.send.is_cuda
+
+    def pack(self, x, cost, basis, status, iters, pivots):
+        """Rows of this rank's slice (device or host tensors of the solver's dtypes) into the send buffer."""
+        t, n, m = self.torch, self.n, self.m
+        cnt = x.shape[0]
+        s = self.send
+        s[:cnt, :n] = x.view(t.int64)
+        s[:cnt, n] = cost.view(t.int64)
+        s[:cnt, n + 1:n + 1 + m] = basis
+        s[:cnt, n + 1 + m] = status.to(t.int64)
+        s[:cnt, n + 2 + m] = iters
+        s[:cnt, n + 3 + m] = pivots
+
+    def all_gather(self):
+        if self.staged:
+            host = self.torch.zeros(self.recv.shape, dtype=self.torch.int64)
+            self.dist.all_gather_into_tensor(host, self.send.cpu(), group=self.group)
+            self.recv.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        return self.recv
+
+    def unpack(self):
+        """The whole batch in LP order as host arrays (x, cost, basis, status, iters, pivots)."""
+        n, m = self.n, self.m
+        rows = []
+        for g in range(self.world):
+            lo, hi = shard(self.total, g, self.world)
+            rows.append(self.recv[g * self.per:g * self.per + (hi - lo)])
+        r = self.torch.cat(rows).cpu().numpy()
+        return dict(x=np.ascontiguousarray(r[:, :n]).view(np.float64), cost=np.ascontiguousarray(r[:, n]).view(np.float64),
+                    basis=np.ascontiguousarray(r[:, n + 1:n + 1 + m]), status=r[:, n + 1 + m].astype(np.int32),
+                    iters=np.ascontiguousarray(r[:, n + 2 + m]), pivots=np.ascontiguousarray(r[:, n + 3 + m]))
+
+
+class ShardedBatch:
+    """A FIXED batch of independent LPs split over the ranks of a process group (BASELINE config 3: 4096 LPs over 1/2/4/8
+    GPUs): rank g builds ``solver_cls`` on the contiguous slice ``shard(B, g, world)`` of the batch-major inputs and solves
+    it with no collective on the data path; ``gather()`` is the one all-gather of the results, after which every rank holds
+    the whole batch -- bit for bit what one rank solving all B LPs returns, since LPs never interact.  Every rank passes the
+    same full arrays (or, with ``local=True``, only its own slice)."""
+
+    def __init__(self, solver_cls, c, A, b, basis, group, local=False, **kw):
+        import torch.distributed as dist
+
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        c, A, b, basis = (np.asarray(v) for v in (c, A, b, basis))
+        if local:
+            counts = [None] * self.world
+            dist.all_gather_object(counts, int(A.shape[0]), group=group)
+            self.total = int(sum(counts))
+            lo, hi = shard(self.total, self.rank, self.world)
+            if hi - lo != A.shape[0]:
+                raise ValueError(f"rank {self.rank} holds {A.shape[0]} LPs, its shard of {self.total} is {hi - lo}")
+            self.lo, self.hi = lo, hi
+        else:
+            self.total = int(A.shape[0])
+            self.lo, self.hi = shard(self.total, self.rank, self.world)
+            c, A, b, basis = c[self.lo:self.hi], A[self.lo:self.hi], b[self.lo:self.hi], basis[self.lo:self.hi]
+        if self.hi == self.lo:
+            raise ValueError("more ranks than LPs: this rank's shard is empty")
+        self.solver = solver_cls(c, A, b, basis, **kw)
+        self.results = ResultGather(group, self.total, self.solver.m, self.solver.n, "cuda")
+
+    def enqueue(self, maxiters):
+        self.solver.enqueue(maxiters)
+
+    def gather(self):
+        """Stream-ordered after the solve: pack this rank's results, all-gather, leave the whole batch in ``results``."""
+        s = self.solver
+        self.results.pack(s.x, s.cost, s.basis, s.status, s.iters, s.pivots)
+        self.results.all_gather()
+
+    def solve(self, maxiters=100):
+        """Solve the shard, gather, and return the whole batch's raw arrays (host) -- on every rank."""
+        self.enqueue(maxiters)
+        self.gather()
+        return self.results.unpack()

@@ -14,8 +14,14 @@ _spec = importlib.util.spec_from_file_location("lpx_problems", os.path.join(ROOT
 gen = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gen)
 
+def gen_columns(m, n, seed):
+    """bench.py's generator (float32 column blocks) in the (c, A, b, basis) order of the others."""
+    A, b, c, basis = gen.gen_primal_columns(m, n, seed, 0, n)
+    return c, A, b, basis
+
+
 GENERATORS = {"gen_primal": gen.gen_primal, "gen_dual": gen.gen_dual, "gen_box": gen.gen_box,
-              "gen_primal_degenerate": gen.gen_primal_degenerate}
+              "gen_primal_degenerate": gen.gen_primal_degenerate, "gen_primal_columns": gen_columns}
 
 # north_star: objective and solution within 1e-9 relative in fp64
 RTOL = 1e-9

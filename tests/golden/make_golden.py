@@ -269,7 +269,7 @@ def gen_columns(m, n, seed):
 def xlarge_cases():
     """Prefixes on matrices large enough for the code paths that only engage on big inputs (staged pricing at A >= 64 MB,
     the fused update + y pass, non-temporal streams, 4-KiB row alignment, multi-strip column gathers), and the bench's own
-    generator at three sizes.  The reference needs 1-3 s per pivot at m = 5000, so these are prefixes (maxiters hit)."""
+    generator at three sizes.  The reference needs about 1 s per pivot at m = 5000 and 8 s at m = 10000 here, so these are prefixes (maxiters hit)."""
     out = []
     PR, DR = primal_solvers.PrimalRevisedSimplexSolver, dual_solvers.DualRevisedSimplexSolver
 
@@ -283,8 +283,9 @@ def xlarge_cases():
 
     add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 64, 128, 0, 100000)
     add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 1000, 2000, 0, 400)
-    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 5000, 10000, 0, 40)
-    add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, 5000, 10000, 0, 40)
+    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 5000, 10000, 0, 120)
+    add("gen_dual", "DualRevisedSimplexSolver", DR, gen.gen_dual, 5000, 10000, 0, 120)
+    add("gen_primal_columns", "PrimalRevisedSimplexSolver", PR, gen_columns, 10000, 20000, 0, 24)  # bench.py's revised10k
     return out
 
 

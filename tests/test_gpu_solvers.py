@@ -10,7 +10,7 @@ from tests._util import assert_close, case_id, gen, load, problem_of, ub_of
 
 pytestmark = pytest.mark.gpu
 
-BASE = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json") + load("degenerate.json")
+BASE = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json") + load("random_xlarge.json") + load("degenerate.json")
         if cs["solver"] in ("PrimalRevisedSimplexSolver", "DualRevisedSimplexSolver", "PrimalNaiveSimplexSolver",
                             "DualNaiveSimplexSolver")]
 
