@@ -179,6 +179,11 @@ int lpx_naive_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream
  * x[n] = scatter of x_B (plus nonbasic bound values when lb/ub are set); cost[0] = dot(c, x). */
 int lpx_revised_expand(const lpx_revised *s, double *x, double *cost, void *stream);
 
+/* Row `row` of the tableau B^-1 A into out[n] (float64): what PhaseOneSimplexSolver reads of
+ * `(solver.inv_basis_matrix @ solver.A)[row, :]` to pivot a basic artificial variable out, special_solvers.py:69-71 --
+ * one row instead of the reference's whole m x n product, and no download of B^-1. */
+int lpx_revised_tableau_row(const lpx_revised *s, int64_t row, double *out, void *stream);
+
 /* BoundedVariablePrimalSimplexSolver._update_bfs, special_solvers.py:169-175. */
 int lpx_bounded_update_bfs(const lpx_revised *s, void *stream);
 

@@ -72,6 +72,7 @@ _SIGS = {
     "lpx_revised_reinvert": (C.c_int, [C.POINTER(LpxRevised), vp]),
     "lpx_naive_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),
     "lpx_revised_expand": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp]),
+    "lpx_revised_tableau_row": (C.c_int, [C.POINTER(LpxRevised), i64, vp, vp]),
     "lpx_bounded_update_bfs": (C.c_int, [C.POINTER(LpxRevised), vp]),
     "lpx_revised_reduced_costs": (C.c_int, [C.POINTER(LpxRevised), C.c_int, vp, vp]),
     "lpx_pd_admissible": (C.c_int, [C.POINTER(LpxRevised), vp, vp, i64, vp, vp]),

@@ -1246,6 +1246,36 @@ extern "C" int lpx_revised_reduced_costs(const lpx_revised *s, int bounded, doub
     return LPX_OK;
 }
 
+// One row of the tableau B^-1 A (special_solvers.py:69-71: PhaseOneSimplexSolver looks for a positive entry in the row of
+// a basic artificial variable to pivot it out; the reference forms the whole m x n product for it).  A thread per column,
+// the weights B^-1[row, :] staged in LDS in chunks, fma in row order.  Independent of the loop's status word.
+#define TROW_CHUNK 1024
+__global__ __launch_bounds__(LPX_BLOCK) void k_tableau_row(lpx_revised s, int64_t row, double *out)
+{
+    __shared__ double w[TROW_CHUNK];
+    const int64_t j = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    double acc = 0.0;
+    for (int64_t i0 = 0; i0 < s.m; i0 += TROW_CHUNK) {
+        const int64_t cnt = (s.m - i0 < TROW_CHUNK) ? s.m - i0 : TROW_CHUNK;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < cnt; i += LPX_BLOCK) w[i] = s.Binv[row * s.ldB + i0 + i];
+        __syncthreads();
+        if (j < s.n)
+            for (int64_t i = 0; i < cnt; ++i) acc = fma(w[i], (double)s.A[(i0 + i) * s.ldA + j], acc);
+    }
+    if (j < s.n) out[j] = acc;
+}
+extern "C" int lpx_revised_tableau_row(const lpx_revised *s, int64_t row, double *out, void *stream)
+{
+    int rc = check_revised(s);
+    if (rc) return rc;
+    LPX_REQUIRE(out != nullptr && row >= 0 && row < s->m, "bad row / null output");
+    hipLaunchKernelGGL(k_tableau_row, dim3((unsigned)lpx_cdiv(s->n, LPX_BLOCK)), dim3(LPX_BLOCK), 0, (hipStream_t)stream, *s,
+                       row, out);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 extern "C" int lpx_revised_expand(const lpx_revised *s, double *x, double *cost, void *stream)
 {
     int rc = check_revised(s);

@@ -33,6 +33,9 @@ struct Rank1Args {
     // slot handed to the leaving variable is rewritten with the eta column instead of a unit vector
     const int64_t *slot_var;
     const int64_t *var_slot;
+    // ragged last strip folded into its neighbour: the workgroups of the last strip make a second pass over the few
+    // columns left beyond it (20001 = 39 x 512 + 33: a 40th workgroup per row with 17 live lanes costs as much as a full one)
+    int fold;
 };
 
 template <int NT>
@@ -81,7 +84,12 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
         }
     }
 
-    const int64_t colbase = ((int64_t)blockIdx.x * (nthr * VPT) + threadIdx.x) * 2;
+    const int npass = (a.fold && blockIdx.x == gridDim.x - 1) ? 2 : 1;
+    const bool pricing_wg = TABLEAU && a.price_v0 != nullptr && row1 == a.rows; // workgroup-uniform
+    double mn = LPX_INF;
+    int64_t jn = LPX_NOIDX;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int64_t colbase = (((int64_t)blockIdx.x + pass) * (nthr * VPT) + threadIdx.x) * 2;
     d2_t pr[VPT];
     bool live[VPT], fix0[VPT], fix1[VPT];
 #pragma unroll
@@ -157,10 +165,7 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
     }
     } // live[0]
 
-    if (TABLEAU && a.price_v0 != nullptr && row1 == a.rows) { // workgroup-uniform
-        __shared__ BlockRed red;
-        double mn = LPX_INF;
-        int64_t jn = LPX_NOIDX;
+    if (pricing_wg) { // this pass's part of the new reduced-cost row
         const int64_t nstruct = a.cols - 1; // column cols-1 is x_B / -objective
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
@@ -179,6 +184,11 @@ __global__ __launch_bounds__(1024) void k_rank1(Rank1Args a)
                 }
             }
         }
+    }
+    } // pass
+
+    if (pricing_wg) {
+        __shared__ BlockRed red;
         if (a.pricing == LPX_PRICE_DANTZIG) {
             const VI t = block_argmin(VI{mn, jn}, red);
             mn = t.v;
@@ -285,6 +295,7 @@ struct Rank1Plan {
     dim3 grid;
     int64_t rows_per_block;
     int vpt, unroll, nt, threads;
+    int fold; // the last strip's workgroups also cover the ragged remainder (Rank1Args.fold)
 };
 static inline int lpx_env_int(const char *name, int dflt)
 {
@@ -307,7 +318,11 @@ static inline Rank1Plan lpx_rank1_plan(int64_t rows, int64_t cols)
     if (p.vpt != 2 && p.vpt != 4) p.vpt = 1;
     if (p.unroll != 1 && p.unroll != 2 && p.unroll != 8 && p.unroll != 16) p.unroll = 4;
     if (p.nt < 0 || p.nt > 3) p.nt = 0;
-    const int64_t nstrips = lpx_cdiv(cols, 2 * (int64_t)p.threads * p.vpt);
+    int64_t nstrips = lpx_cdiv(cols, 2 * (int64_t)p.threads * p.vpt);
+    // a remainder of at most a quarter strip is folded into the strip before it
+    const int64_t strip = 2 * (int64_t)p.threads * p.vpt, rem = cols - (nstrips - 1) * strip;
+    p.fold = (lpx_env_int("LPX_RANK1_FOLD", 1) != 0 && nstrips > 1 && 4 * rem <= strip) ? 1 : 0;
+    nstrips -= p.fold;
     // small problems: shrink the tile until there are enough workgroups to occupy the chip
     const int64_t minwg = lpx_env_int("LPX_RANK1_MINWG", 1024);
     while (rpb > 4 && nstrips * lpx_cdiv(rows, rpb) < minwg) rpb /= 2;
@@ -320,6 +335,7 @@ template <bool TABLEAU>
 static inline void lpx_rank1_launch(const Rank1Plan &p, Rank1Args a, hipStream_t st)
 {
     a.rows_per_block = p.rows_per_block;
+    a.fold = p.fold;
 #define LPX_R1_GO(NT, VPT, UN) hipLaunchKernelGGL((k_rank1<TABLEAU, NT, VPT, UN>), p.grid, dim3(p.threads), 0, st, a)
 #define LPX_R1_UN(NT, VPT)                          \
     switch (p.unroll) {                             \

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price(lpx_tableau s, Partials P
     __shared__ BlockRed red;
     if (s.ctrl->status != LPX_RUNNING) return;
     const int64_t c0 = (int64_t)blockIdx.x * strip;
-    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    const int64_t c1 = (blockIdx.x == gridDim.x - 1) ? s.n : c0 + strip; // the last strip may be folded (lpx_rank1.hpp)
     double mn = LPX_INF;
     int64_t jn = LPX_NOIDX;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_price_next(lpx_tableau s, Parti
     const int64_t unit = t_unit_col(s);
     const double em = e[s.m];
     const int64_t c0 = (int64_t)blockIdx.x * strip;
-    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    const int64_t c1 = (blockIdx.x == gridDim.x - 1) ? s.n : c0 + strip; // the last strip may be folded (lpx_rank1.hpp)
     double mn = LPX_INF;
     int64_t jn = LPX_NOIDX;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_ratio(lpx_tableau s, Partials 
     }
     if (opt) return;
     const int64_t c0 = (int64_t)blockIdx.x * strip;
-    const int64_t c1 = (c0 + strip < s.n) ? c0 + strip : s.n;
+    const int64_t c1 = (blockIdx.x == gridDim.x - 1) ? s.n : c0 + strip; // the last strip may be folded (lpx_rank1.hpp)
     VI best{LPX_INF, LPX_NOIDX};
     double rowmin = LPX_INF;
     for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {

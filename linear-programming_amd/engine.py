@@ -127,6 +127,12 @@ class RevisedEngine:
         f = self.lib.lpx_naive_pivot if self.naive else self.lib.lpx_revised_pivot
         _lib.check(f(C.byref(self.s), int(row), int(col), st))
 
+    def tableau_row(self, row):
+        """Row `row` of B^-1 A on the host (n float64): one device pass, O(n) download (special_solvers.py:69-71)."""
+        out = self.torch.empty(self.n, dtype=self.torch.float64, device="cuda")
+        _lib.check(self.lib.lpx_revised_tableau_row(C.byref(self.s), int(row), out.data_ptr(), stream_ptr()))
+        return out.cpu().numpy()
+
     def bounded_update_bfs(self):
         _lib.check(self.lib.lpx_bounded_update_bfs(C.byref(self.s), stream_ptr()))
 

@@ -15,6 +15,7 @@ from .device import stream_ptr, to_device, torch_cuda
 from .engine import RevisedEngine
 from .exceptions import DualIsUnboundedError, PrimalIsInfeasibleError, PrimalIsUnboundedError
 from .preprocessing import ProblemPreprocessingUtils
+from .dual_solvers import DualRevisedSimplexSolver
 from .primal_solvers import PrimalRevisedSimplexSolver, _initial_inverse
 from .utils import get_bounds_on_bfs
 
@@ -50,7 +51,7 @@ class PhaseOneSimplexSolver(PrimalRevisedSimplexSolver):
                     continue
                 row = int(np.argmax(res.basis == art))
                 candidates = np.array([j for j in range(self.n) if j not in res.basis])
-                tableau_row = (solver.inv_basis_matrix[row] @ solver.A)[candidates]
+                tableau_row = solver._engine.tableau_row(row)[candidates]  # B^-1[row, :] @ A on the device (:69-71)
                 usable = tableau_row > 0
                 if usable.any():
                     solver.pivot(row, candidates[np.argmax(usable)])
@@ -123,11 +124,11 @@ class BoundedVariablePrimalSimplexSolver(PrimalRevisedSimplexSolver):
             raise ValueError("Column to enter basis is not nonbasic.")  # :331
 
 
-class PrimalDualAlgorithm:
+class PrimalDualAlgorithm(DualRevisedSimplexSolver):
     """Primal-dual algorithm (special_solvers.py:346-480).
 
-    The reference derives from DualRevisedSimplexSolver but overrides both ``__init__`` and ``solve`` and
-    uses nothing else of it.
+    As in the reference it derives from DualRevisedSimplexSolver (``isinstance`` checks agree) but overrides both
+    ``__init__`` and ``solve`` and uses nothing else of it: no engine of the base class is ever built.
     """
 
     def __init__(self, c, A, b):

@@ -1,7 +1,7 @@
 """Host scalar helpers (reference: linprog/utils.py:5-40).
 
 ``primal_simplex_div`` / ``dual_simplex_div`` are the ratio-test arithmetic; on the device path they live
-inside the ratio kernels (csrc/lpx_reduce.hip).  The NumPy forms here exist for API completeness (the
+inside the ratio kernels (csrc/lpx_core.hip: k_direction / lpx_psd, lpx_dsd in csrc/lpx_device.hpp).  The NumPy forms here exist for API completeness (the
 reference exports them) and are array expressions rather than per-element Python calls.
 """
 from math import factorial

@@ -73,3 +73,30 @@ def test_generators_are_partition_invariant():
     parts = np.hstack([gen.gen_primal_columns(40, 100, 7, j, min(j + 13, 100))[0] for j in range(0, 100, 13)])
     assert np.array_equal(full, parts)
     assert np.array_equal(full[:, 60:], np.eye(40, dtype=np.float32))
+
+
+def test_iterate_without_a_device_fails_cleanly_and_repeatably():
+    """No GPU here: a loop entry point whose arguments pass validation must come back with LPX_E_HIP from the first HIP
+    call (never crash, never leave library state behind that makes the next call behave differently)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from linprog_amd import _lib
+
+    L = _lib.load()
+    m, n = 8, 16
+    ws = L.lpx_tableau_workspace_bytes(m, n)
+    buf = (C.c_char * (ws + 64))()
+    T = (C.c_double * ((m + 1) * (n + 2)))()
+    ints = (C.c_int64 * 64)()
+    base = C.addressof(buf) + (-C.addressof(buf)) % 16
+    s = _lib.LpxTableau()
+    s.m, s.n, s.ld, s.col0, s.n_global, s.pricing = m, n, n + 2, 0, n, 0
+    s.T, s.basis, s.var_state, s.ctrl = C.addressof(T), C.addressof(ints), C.addressof(ints), C.addressof(ints)
+    s.workspace, s.workspace_bytes = base, ws
+    for _ in range(2):
+        rc = L.lpx_tableau_iterate(C.byref(s), 64, None)
+        assert rc in (-2, -1), rc  # LPX_E_HIP (no device) -- or LPX_E_ARG if alignment of the fake buffers is refused
+        assert L.lpx_last_error()
+    assert L.lpx_tableau_iterate(C.byref(s), 0, None) == 0  # nothing to do: no HIP call at all

@@ -225,3 +225,37 @@ def test_plain_c_client_of_the_abi():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "c abi demo ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_graph_capture_failure_unwinds_and_the_next_call_works(env, monkeypatch):
+    """lpx_graph.hpp: an error inside a captured chain is returned (LPX_E_ARG) with the capture ended and the graph
+    destroyed, and a failing capture / instantiation falls back to eager launches; in both cases the per-device capture
+    stream is usable again, so the next call captures and replays as usual.  LPX_GRAPH_TEST_FAIL is the test hook."""
+    import ctypes as C
+
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+    from tests._util import gen
+
+    lib, L = env["lib"], env["L"]
+    c, A, b, basis = gen.gen_primal(40, 100, 3)
+    want = O.OracleTableau(c, A, b, basis, condensed=True, log_cap=512)
+    s = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": 512})(c, A, b, basis)
+    eng = s._engine
+    st = env["torch"].cuda.current_stream().cuda_stream
+    lib.check(L.lpx_ctrl_begin_solve(eng.s.ctrl, st))
+    monkeypatch.setenv("LPX_GRAPH_UNROLL", "6")  # a key of its own: nothing cached from other tests
+    monkeypatch.setenv("LPX_GRAPH_TEST_FAIL", "arg")
+    assert L.lpx_tableau_iterate(C.byref(eng.s), 12, st) == -1  # LPX_E_ARG out of the captured chain
+    assert b"captured chain" in L.lpx_last_error()
+    env["torch"].cuda.synchronize()
+    done = int(eng.read_ctrl().pivots)  # whatever ran before the failure is a valid prefix of the solve
+    monkeypatch.setenv("LPX_GRAPH_TEST_FAIL", "hip")
+    lib.check(L.lpx_tableau_iterate(C.byref(eng.s), 12, st))  # capture "fails": eager fallback, all 12 iterations run
+    assert int(eng.read_ctrl().pivots) == done + 12
+    monkeypatch.delenv("LPX_GRAPH_TEST_FAIL")
+    lib.check(L.lpx_tableau_iterate(C.byref(eng.s), 12, st))  # captures and replays
+    total = done + 24
+    assert int(eng.read_ctrl().pivots) == total
+    want.solve(total)
+    assert s.pivot_log().tolist() == want.log[:total].tolist()

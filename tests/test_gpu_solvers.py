@@ -201,6 +201,44 @@ def test_two_phase_driver(cs):
     assert_close(res.cost, ref["cost"], "cost")
 
 
+def test_tableau_row_entry_point_and_artificial_drive_out():
+    """lpx_revised_tableau_row = (inv_basis_matrix @ A)[row, :] (special_solvers.py:69-71) without downloading B^-1, and
+    PhaseOneSimplexSolver's drive-out built on it: on LPs with a duplicated equation an artificial variable stays basic
+    at zero level after phase one; it is pivoted out where the tableau row has a positive entry, else its (redundant) row
+    is dropped -- either way the basis handed to phase two is a feasible basis of the rows that are kept."""
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from linprog_amd.special_solvers import PhaseOneSimplexSolver
+
+    c, A, b, basis = gen.gen_primal(40, 90, 21)
+    s = PrimalRevisedSimplexSolver(c, A, b, basis)
+    s.solve(25)
+    T = s.inv_basis_matrix @ s.A.astype(np.float64)
+    for row in (0, 17, 39):
+        got = s._engine.tableau_row(row)
+        assert np.allclose(got, T[row], rtol=1e-12, atol=1e-12)
+    # redundant equations with small integer data (every pivot exact): expected bases and kept rows are the reference's
+    # PhaseOneSimplexSolver on the same inputs (run in the build container)
+    cases = [
+        ([[1, 0, 0, 1, 0, 0], [0, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 1], [1, 1, 0, 1, 1, 0]], [2, 3, 1, 5], [0, 1, 2], 3),
+        ([[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]], [2, 2, 3], [0, 2], 2),
+        ([[1, 2, 1, 0, 0], [2, 4, 2, 0, 0], [0, 1, 0, 1, 0], [1, 0, 0, 0, 1]], [4, 8, 3, 2], [1, 3, 0], 3),
+        ([[1, 1, 1, 0], [1, -1, 0, 1], [2, 0, 1, 1]], [4, 0, 4], [1, 0], 2),
+    ]
+    for A, b, want_basis, want_m in cases:
+        A, b = np.array(A, dtype=float), np.array(b, dtype=float)
+        p1 = PhaseOneSimplexSolver(np.zeros(A.shape[1]), A, b)
+        p1.solve(1000)
+        assert p1.basis.tolist() == want_basis and int(p1.m) == want_m and p1.A.shape[0] == want_m
+
+
+def test_primal_dual_is_a_dual_revised_solver_like_the_reference():
+    """special_solvers.py:346: class PrimalDualAlgorithm(DualRevisedSimplexSolver)."""
+    from linprog_amd.dual_solvers import DualRevisedSimplexSolver
+    from linprog_amd.special_solvers import PrimalDualAlgorithm
+
+    assert issubclass(PrimalDualAlgorithm, DualRevisedSimplexSolver)
+
+
 def test_full_size_config2_properties():
     """BASELINE config 2 (m=1000, n=2000): size-independent properties of a pivot window, plus the oracle's
     pivot sequence on the same window."""
