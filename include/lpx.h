@@ -163,6 +163,20 @@ int64_t lpx_revised_workspace_bytes(int64_t m, int64_t n);
  *   BoundedVariablePrimalSimplexSolver.solve    special_solvers.py:225-341. */
 int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *stream);
 
+/* The same loops as ONE launch for a small LP (kind = LPX_KIND_PRIMAL, LPX_KIND_DUAL or LPX_KIND_BOUNDED): a whole solve()
+ * call -- up to `maxiters` iterations of primal_solvers.py:191-207 / dual_solvers.py:96-106 / special_solvers.py:225-341 --
+ * by one workgroup with B^-1 in LDS, state read from and written back to *s (control block included; call
+ * lpx_ctrl_begin_solve first, as for lpx_revised_iterate).  A single LP of a few hundred rows is launch-bound on the
+ * multi-kernel chain (~40 us per iteration whatever its size); here an iteration costs a few microseconds.
+ * lpx_revised_small_lds_bytes(m, n, kind) <= 158 KiB says whether a shape fits (m <= 128 at n = 2m), else LPX_E_SIZE.
+ * Dot products are accumulated in index order with fma: bit-identical to the oracle's loops.
+ * lpx_revised_solve_small_batch: `batch` such states (a DEVICE array of lpx_revised, all m x n), one workgroup each; x
+ * (batch x n) and cost (batch) receive the expanded solutions when non-NULL (special_solvers.py:201-206 for bounded). */
+int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind);
+int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t maxiters, void *stream);
+int lpx_revised_solve_small_batch(const lpx_revised *dev_states, int64_t batch, int64_t m, int64_t n, int kind,
+                                  int64_t maxiters, double *x, double *cost, void *stream);
+
 /* PrimalRevisedSimplexSolver.pivot(row, col), primal_solvers.py:255-263 (called from outside the loop by
  * PhaseOneSimplexSolver, special_solvers.py:77-79). */
 int lpx_revised_pivot(const lpx_revised *s, int64_t row, int64_t col, void *stream);
@@ -198,9 +212,12 @@ int lpx_pd_admissible(const lpx_revised *s, const double *y, const double *c64, 
                       void *stream);
 /* special_solvers.py:430-444: y_rp = c_B B^-1 of the solved restricted primal; u = y_rp @ A;
  * out[0] = theta = min over excluded j with u_j > 0 of (c64_j - v_j)/u_j ; out[1] = max(u_j over admissible j,
- * y_rp_i) (dual unbounded iff <= 0, :435-436); then y += theta * y_rp unless out[1] <= 0. */
+ * y_rp_i) (dual unbounded iff <= 0, :435-436); then y += theta * y_rp unless out[1] <= 0.
+ * cost_gate (device pointer or NULL): the restricted primal's cost as lpx_revised_expand left it -- the reference takes
+ * this step only while it is > 0 (:427) and stops otherwise (:445-447); with the gate the host need not fetch the cost
+ * before enqueueing the step: y is left alone when *cost_gate <= 0, and out[2] = *cost_gate (out has 3 doubles then). */
 int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c64, const double *v, int64_t n_orig,
-                     double *out, void *stream);
+                     double *out, const double *cost_gate, void *stream);
 
 /* ----------------------------------------------------------------------------- tableau-form solver loop */
 int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);

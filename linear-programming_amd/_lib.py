@@ -67,6 +67,9 @@ _SIGS = {
     "lpx_profile_k1_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
     "lpx_revised_workspace_bytes": (i64, [i64, i64]),
     "lpx_revised_iterate": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
+    "lpx_revised_small_lds_bytes": (i64, [i64, i64, C.c_int]),
+    "lpx_revised_solve_small": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
+    "lpx_revised_solve_small_batch": (C.c_int, [vp, i64, i64, i64, C.c_int, i64, vp, vp, vp]),
     "lpx_revised_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),
     "lpx_naive_workspace_bytes": (i64, [i64]),
     "lpx_revised_reinvert": (C.c_int, [C.POINTER(LpxRevised), vp]),
@@ -76,7 +79,7 @@ _SIGS = {
     "lpx_bounded_update_bfs": (C.c_int, [C.POINTER(LpxRevised), vp]),
     "lpx_revised_reduced_costs": (C.c_int, [C.POINTER(LpxRevised), C.c_int, vp, vp]),
     "lpx_pd_admissible": (C.c_int, [C.POINTER(LpxRevised), vp, vp, i64, vp, vp]),
-    "lpx_pd_dual_step": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp, i64, vp, vp]),
+    "lpx_pd_dual_step": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp, i64, vp, vp, vp]),
     "lpx_tableau_workspace_bytes": (i64, [i64, i64]),
     "lpx_tableau_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
     "lpx_tableau_msg_len": (i64, [i64]),

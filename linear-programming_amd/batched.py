@@ -218,6 +218,108 @@ class BatchedDualTableauSolver(BatchedDualSolver):
             int(maxiters), self.log.data_ptr() if self.log_cap else None, self.log_cap, stream_ptr()))
 
 
+class BatchedBoundedSolver:
+    """``BoundedVariablePrimalSimplexSolver(c, A, b, lb, ub, basis, lb_nonbasic_vars, ub_nonbasic_vars).solve(maxiters)``
+    (special_solvers.py:94-343) for a batch of box-bounded LPs of one shape: one workgroup per LP runs the whole bounded
+    loop -- float32-rounded reduced costs with the largest-coefficient rule, the three-way ratio test, bound flips, x_B
+    recomputed from scratch every iteration -- with B^-1 in LDS (``lpx_revised_solve_small_batch``; m <= 128 at n = 2m).
+    Batch-major inputs: c (B, n), A (B, m, n), b (B, m), lb / ub (B, n), basis (B, m), var_state (B, n) with
+    ``_lib.VS_LOWER / VS_UPPER`` for the nonbasic variables (anything else: not enterable, as a variable in neither of the
+    reference's two lists).  Infinite bounds are replaced per LP as the reference does (:139-142).  Bit-identical per LP to
+    the oracle's ``lpo_bounded_solve``; a batch cannot raise per LP: ``raw["status"]`` tells unbounded LPs apart."""
+
+    def __init__(self, c, A, b, lb, ub, basis, var_state, log_cap=0):
+        from .utils import get_bounds_on_bfs
+
+        torch = torch_cuda()
+        self.torch = torch
+        self.lib = _lib.load()
+        c32 = np.asarray(c).astype(np.float32)
+        A32 = np.array(A).astype(np.float32)
+        b32 = np.array(b).astype(np.float32)
+        neg = b32 < 0  # preprocessing.py:11-13, per LP
+        A32[neg] *= -1
+        b32[neg] *= -1
+        self.B, self.m, self.n = A32.shape
+        B, m, n = self.B, self.m, self.n
+        lb = np.array(lb, dtype=np.float64)
+        ub = np.array(ub, dtype=np.float64)
+        for i in range(B):  # special_solvers.py:139-142
+            if np.isinf(lb[i]).any() or np.isinf(ub[i]).any():
+                M = get_bounds_on_bfs(A32[i], b32[i])
+                lb[i][lb[i] == -np.inf] = -M
+                ub[i][ub[i] == np.inf] = M
+        basis = np.asarray(basis).astype(np.int64)
+        vs = np.array(var_state, dtype=np.int32)
+        vs[(vs != _lib.VS_LOWER) & (vs != _lib.VS_UPPER)] = _lib.VS_EXCLUDED
+        np.put_along_axis(vs, basis, _lib.VS_BASIC, axis=1)
+        Bmat = np.take_along_axis(A32, basis[:, None, :], axis=2)
+        if np.array_equal(Bmat, np.broadcast_to(np.eye(m, dtype=np.float32), Bmat.shape)):
+            inv = np.broadcast_to(np.eye(m), (B, m, m))
+        else:
+            inv = np.stack([np.linalg.inv(Bmat[i]) for i in range(B)]).astype(np.float64)  # float32 inverse, :144
+        self.ldA, self.ldB = n, m
+        self.A, self.b, self.c = to_device(np.ascontiguousarray(A32)), to_device(b32), to_device(c32)
+        self.At = self.A.transpose(1, 2).contiguous()  # column j of A contiguous: coalesced row reads in the kernel
+        self.lb, self.ub = to_device(lb), to_device(ub)
+        self.Binv = to_device(np.ascontiguousarray(inv, dtype=np.float64))
+        self.xB = torch.zeros((B, m), dtype=torch.float64, device="cuda")
+        self.basis, self.var_state = to_device(basis), to_device(vs)
+        self.ctrl = torch.zeros((B, 128), dtype=torch.uint8, device="cuda")
+        self.log_cap = int(log_cap)
+        self.log = torch.zeros((B, max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
+        self.x = torch.zeros((B, n), dtype=torch.float64, device="cuda")
+        self.cost = torch.zeros(B, dtype=torch.float64, device="cuda")
+        # one lpx_revised per LP, pointing into the batch-major tensors, as a device array
+        import ctypes as C
+
+        arr = (_lib.LpxRevised * B)()
+        for i in range(B):
+            s = arr[i]
+            s.m, s.n, s.ldA, s.ldAt, s.ldB = m, n, n, m, m
+            s.A, s.At = self.A[i].data_ptr(), self.At[i].data_ptr()
+            s.b, s.c = self.b[i].data_ptr(), self.c[i].data_ptr()
+            s.Binv, s.xB = self.Binv[i].data_ptr(), self.xB[i].data_ptr()
+            s.basis, s.var_state = self.basis[i].data_ptr(), self.var_state[i].data_ptr()
+            s.lb, s.ub, s.ctrl = self.lb[i].data_ptr(), self.ub[i].data_ptr(), self.ctrl[i].data_ptr()
+            s.log = self.log[i].data_ptr() if self.log_cap else None
+            s.log_cap = self.log_cap
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.states = to_device(raw)
+        # x_B of the starting state, B^-1 (b - A_lb lb - A_ub ub) (special_solvers.py:145), is formed by the kernel itself
+        flags = np.zeros((B, 128), dtype=np.uint8)
+        flags[:, 4] = 1  # lpx_ctrl.f32_phase = 1 (little endian int32 at offset 4); status RUNNING, counters 0
+        self.ctrl.copy_(to_device(flags))
+
+    def enqueue(self, maxiters):
+        _lib.check(self.lib.lpx_revised_solve_small_batch(self.states.data_ptr(), self.B, self.m, self.n, _lib.KIND_BOUNDED,
+                                                          int(maxiters), self.x.data_ptr(), self.cost.data_ptr(), stream_ptr()))
+
+    def results(self):
+        ctrl = self.ctrl.cpu().numpy()
+        status = ctrl[:, 0:4].copy().view(np.int32)[:, 0]
+        iters = ctrl[:, 8:16].copy().view(np.int64)[:, 0]
+        pivots = ctrl[:, 16:24].copy().view(np.int64)[:, 0]
+        return dict(x=self.x.cpu().numpy(), cost=self.cost.cpu().numpy(), basis=self.basis.cpu().numpy(), status=status,
+                    iters=iters, pivots=pivots, var_state=self.var_state.cpu().numpy())
+
+    def solve(self, maxiters=100):
+        """One solve() call per LP (a second call continues from the state the first one left, as the reference's)."""
+        # a new call restarts the per-call iteration counter and the status (primal_solvers.py:189-190)
+        flags = self.ctrl.clone()
+        flags[:, 0:4] = 0
+        flags[:, 8:16] = 0
+        self.ctrl.copy_(flags)
+        self.enqueue(maxiters)
+        self.raw = r = self.results()
+        return [LinProgResult(x=r["x"][i], basis=r["basis"][i], cost=np.float64(r["cost"][i]), iters=int(r["iters"][i]),
+                              optimum=bool(r["status"][i] == _lib.OPTIMAL)) for i in range(self.B)]
+
+    def pivot_logs(self):
+        p, lg = self.raw["pivots"], self.log.cpu().numpy()
+        return [lg[i, : min(int(p[i]), self.log_cap)] for i in range(self.B)]
+
+
 def solve_many(problems, maxiters=100, form="revised"):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
     launches of different shapes run on separate streams, results come back in input order.  ``form="tableau"``: groups

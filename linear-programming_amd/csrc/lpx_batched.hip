@@ -163,6 +163,53 @@ __device__ __forceinline__ AccT batch_dot(const TA *pa, int sa, const TB *pb, in
     return acc;
 }
 
+// The same sequential dot product with operand b in GLOBAL memory (stride sb): a lone workgroup has nothing to hide an L2
+// round trip behind, so DEPTH loads are in flight before the first dependent fma (8 at a time costs one round trip per 8
+// steps: 6 us per pass at m = 128).  Same order of operations, same bits.
+template <typename AccT, int DEPTH, typename TA, typename TB>
+__device__ __forceinline__ AccT block_dot_g(const TA *pa, int sa, const TB *pb, int64_t sb, int len)
+{
+    AccT acc = (AccT)0;
+    int k = 0;
+    for (; k + DEPTH <= len; k += DEPTH) {
+        TB y[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) y[u] = pb[(int64_t)(k + u) * sb];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) acc = fma((AccT)pa[(k + u) * sa], (AccT)y[u], acc);
+    }
+    if (k < len) {
+        TB y[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) y[u] = (k + u < len) ? pb[(int64_t)(k + u) * sb] : (TB)0;
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (k + u < len) acc = fma((AccT)pa[(k + u) * sa], (AccT)y[u], acc);
+    }
+    return acc;
+}
+
+// two such dot products against the same global operand in one pass over its loads
+template <typename AccT, int DEPTH, typename TA, typename TB>
+__device__ __forceinline__ void block_dot2_g(const TA *pa1, const TA *pa2, const TB *pb, int64_t sb, int len, AccT &o1, AccT &o2)
+{
+    AccT a1 = (AccT)0, a2 = (AccT)0;
+    for (int k = 0; k < len; k += DEPTH) {
+        TB y[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) y[u] = (k + u < len) ? pb[(int64_t)(k + u) * sb] : (TB)0;
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (k + u < len) {
+                a1 = fma((AccT)pa1[k + u], (AccT)y[u], a1);
+                a2 = fma((AccT)pa2[k + u], (AccT)y[u], a2);
+            }
+        }
+    }
+    o1 = a1;
+    o2 = a2;
+}
+
 __global__ __launch_bounds__(LPX_BLOCK) void k_batched_primal(BatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -817,4 +864,403 @@ extern "C" int lpx_batched_dual_solve(int64_t batch, int64_t m, int64_t n, const
     if (n <= 64) return batched_wave_launch<1, double, true>(a, (hipStream_t)stream);
     if (n <= 128) return batched_wave_launch<2, double, true>(a, (hipStream_t)stream);
     return batched_wave_launch<4, float, true>(a, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Whole-solve kernel for ONE small LP in revised form: a solve() call of PrimalRevisedSimplexSolver (primal_solvers.py:
+// 176-263), DualRevisedSimplexSolver (dual_solvers.py:82-120) or BoundedVariablePrimalSimplexSolver (special_solvers.py:
+// 221-343) as a single launch.  The multi-kernel chain of lpx_revised_iterate costs 5-9 launches (~40 us) per iteration
+// whatever the size; a lone LP of a few hundred rows is latency-bound, so here one 256-lane workgroup loads the solver
+// state (lpx_revised: B^-1, x_B, basis, var_state, control block) into LDS, runs the loop to the end and writes the
+// state back.  B^-1 lives in LDS (m x (m+1) fp64: m <= 128 at n = 2m), A stays in global memory (read-only, cached).
+// A batch of such states (an array of lpx_revised on the device) runs as one workgroup each.
+// Arithmetic = the oracle's: every dot product accumulated by one lane in index order with fma, so pivot logs, B^-1, x_B
+// and the per-variable states are bit-identical to lpo_primal_solve / lpo_dual_solve / lpo_bounded_solve.
+// ---------------------------------------------------------------------------------------------------------
+struct BlockArgs {
+    lpx_revised single;          // used when states == nullptr
+    const lpx_revised *states;   // device array, one per workgroup, all of the same m and n
+    int64_t maxiters;
+    double *x, *cost;            // optional per-LP results (batch-major: x is batch x n), or NULL
+};
+struct BlockLds {
+    double *Binv, *xB, *y, *d, *e, *rowr, *w, *rc, *row, *lb, *ub, *bu;
+    float *c, *cb;
+    int *basis, *vstate;
+    int64_t ldb, bytes;
+};
+__host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int kind, char *base)
+{
+    BlockLds L;
+    char *p = base;
+    auto take = [&](int64_t bytes) {
+        char *q = p;
+        p += (bytes + 15) / 16 * 16;
+        return q;
+    };
+    L.ldb = m + 1;
+    L.Binv = (double *)take(8 * m * L.ldb);
+    L.xB = (double *)take(8 * m);
+    L.y = (double *)take(8 * m);
+    L.d = (double *)take(8 * m);
+    L.e = (double *)take(8 * m);
+    L.rowr = (double *)take(8 * m);
+    L.w = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * m : 0);
+    L.rc = (double *)take(8 * n);
+    L.row = (double *)take(kind == LPX_KIND_DUAL ? 8 * n : 0);
+    L.lb = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
+    L.ub = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
+    L.bu = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
+    L.c = (float *)take(4 * n);
+    L.cb = (float *)take(4 * m);
+    L.basis = (int *)take(4 * m);
+    L.vstate = (int *)take(4 * n);
+    L.bytes = (int64_t)(p - base);
+    return L;
+}
+#define LPX_BLOCK_LDS_MAX (158 * 1024)
+
+template <int KIND>
+__global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ BatchRed red;
+    const lpx_revised s = a.states ? a.states[blockIdx.x] : a.single;
+    lpx_ctrl *ctrl = s.ctrl;
+    if (ctrl->status != LPX_RUNNING) return;
+    const int m = (int)s.m, n = (int)s.n, t = threadIdx.x;
+    const int64_t ldA = s.ldA;
+    const BlockLds L = block_lds(m, n, KIND, smem);
+    const int ldb = (int)L.ldb;
+    const float *A = s.A;
+
+    // ---- solver state into LDS
+    for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
+        const int i = idx / m, k = idx - i * m;
+        L.Binv[i * ldb + k] = s.Binv[(int64_t)i * s.ldB + k];
+    }
+    for (int j = t; j < n; j += LPX_BLOCK) {
+        L.c[j] = s.c[j];
+        L.vstate[j] = s.var_state[j];
+        if (KIND == LPX_KIND_BOUNDED) {
+            L.lb[j] = s.lb[j];
+            L.ub[j] = s.ub[j];
+        }
+    }
+    if (t < m) {
+        L.basis[t] = (int)s.basis[t];
+        L.xB[t] = s.xB[t];
+    }
+    __syncthreads();
+    if (t < m) L.cb[t] = L.c[L.basis[t]];
+    bool f32 = ctrl->f32_phase != 0;
+    int status = LPX_RUNNING;
+    int64_t counter = ctrl->counter, pivots = ctrl->pivots;
+    int last_j = -1, last_r = -1, last_leaving = -1, last_flip = 0, last_lstate = 0;
+    double last_price = 0.0;
+    __syncthreads();
+
+    // x_B = B^-1 (b - A_lb lb - A_ub ub) from scratch, special_solvers.py:169-175 (bounded solver: after every iteration, and
+    // once at the start -- a function of the state alone, so recomputing it here equals the value the constructor or the
+    // previous call left, in this kernel's own summation order)
+    auto bounded_update_bfs = [&]() {
+        // The two sums run over ALL columns with the bound of a column that is not at that bound replaced by 0:
+        // fma(a, 0, acc) == acc bit for bit (acc is never -0.0: it starts at +0.0 and an exact cancellation rounds
+        // to +0.0), so the selection costs no branch inside the chain.  Row t of A is read as column t of the
+        // transposed copy (coalesced across lanes) when the state has one.
+        for (int col = t; col < n; col += LPX_BLOCK) {
+            const int vs = L.vstate[col];
+            L.rc[col] = (vs == LPX_VS_LOWER) ? L.lb[col] : 0.0;
+            L.bu[col] = (vs == LPX_VS_UPPER) ? L.ub[col] : 0.0;
+        }
+        __syncthreads();
+        if (t < m) {
+            double accl, accu;
+            if (s.At != nullptr) block_dot2_g<double, 32>(L.rc, L.bu, s.At + t, s.ldAt, n, accl, accu);
+            else block_dot2_g<double, 32>(L.rc, L.bu, A + (int64_t)t * ldA, (int64_t)1, n, accl, accu);
+            L.w[t] = ((double)s.b[t] - accl) - accu;
+        }
+        __syncthreads();
+        if (t < m) L.xB[t] = batch_dot<double>(L.Binv + t * ldb, 1, L.w, 1, m);
+        __syncthreads();
+    };
+    if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs();
+
+    for (int64_t it = 0; it < a.maxiters; ++it) {
+        counter += 1;
+        int r = 0, j = 0;
+        if (KIND == LPX_KIND_DUAL) { // dual_solvers.py:47-54: min(x_B), first row with x_B < 0
+            double mn = (t < m) ? L.xB[t] : LPX_INF;
+            int first = (t < m && mn < 0.0) ? t : 0x7FFFFFFF;
+            batch_min_imin(mn, first, red);
+            last_price = mn;
+            if (lpx_is_optimal_min(mn)) {
+                status = LPX_OPTIMAL;
+                break;
+            }
+            r = first;
+        }
+        // ---- y = c_B @ B^-1 (primal_solvers.py:64, first product): one lane per column, i ascending
+        if (t < m)
+            L.y[t] = f32 ? (double)batch_dot<float>(L.cb, 1, L.Binv + t, ldb, m) : (double)batch_dot<double>(L.cb, 1, L.Binv + t, ldb, m);
+        __syncthreads();
+        // ---- reduced costs, one lane per column (columns t, t + 256, ...), and the rule's reduction
+        if (KIND == LPX_KIND_PRIMAL) { // :64-65, :135-142
+            double mn = LPX_INF;
+            int jn = 0x7FFFFFFF;
+            for (int col = t; col < n; col += LPX_BLOCK) {
+                const int vs = L.vstate[col];
+                if (vs == LPX_VS_EXCLUDED) continue; // restricted primal of the primal-dual algorithm
+                double rc = f32 ? (double)(L.c[col] - block_dot_g<float, 32>(L.y, 1, A + col, ldA, m))
+                                : (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+                if (vs == LPX_VS_BASIC) rc = 0.0;
+                mn = fmin(mn, rc);
+                if (rc < 0.0 && col < jn) jn = col;
+            }
+            batch_min_imin(mn, jn, red);
+            last_price = mn;
+            if (lpx_is_optimal_min(mn)) { // :140-142
+                status = LPX_OPTIMAL;
+                break;
+            }
+            j = jn;
+        } else if (KIND == LPX_KIND_DUAL) { // dual_solvers.py:37-40, :61-80
+            double th = LPX_INF, rowmin = LPX_INF;
+            int jn = 0x7FFFFFFF;
+            for (int col = t; col < n; col += LPX_BLOCK) {
+                const int vs = L.vstate[col];
+                if (vs == LPX_VS_EXCLUDED) continue;
+                double rc, row; // two passes: sharing the loads of A between the two chains measured slower (16 vs 10 us)
+                if (f32) {
+                    rc = (double)(L.c[col] - block_dot_g<float, 32>(L.y, 1, A + col, ldA, m));
+                    row = (double)block_dot_g<float, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                } else {
+                    rc = (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+                    row = block_dot_g<double, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                }
+                if (vs == LPX_VS_BASIC) rc = row = 0.0;
+                const double tj = lpx_dsd(rc, row, f32);
+                if (tj < th || (tj == th && col < jn)) { th = tj; jn = col; }
+                rowmin = fmin(rowmin, row);
+            }
+            double negmin = -rowmin;
+            batch_argmin_max(th, jn, negmin, red); // first argmin of theta; max(-row) = -min(row)
+            if (-negmin >= 0.0) { // dual_solvers.py:41-44
+                status = LPX_DUAL_UNBOUNDED;
+                break;
+            }
+            j = jn;
+        } else { // special_solvers.py:177-214: float32 reduced-cost array, first argmax
+            double best = LPX_INF; // argmin of (-rc, col) == first argmax of rc
+            int jn = 0x7FFFFFFF;
+            for (int col = t; col < n; col += LPX_BLOCK) {
+                const int vs = L.vstate[col];
+                double rc = 0.0;
+                if (vs != LPX_VS_BASIC) {
+                    float tt;
+                    if (f32) tt = (-L.c[col]) + block_dot_g<float, 32>(L.y, 1, A + col, ldA, m);
+                    else tt = (float)((double)(-L.c[col]) + block_dot_g<double, 32>(L.y, 1, A + col, ldA, m));
+                    rc = (vs == LPX_VS_UPPER) ? (double)(-tt) : (double)tt;
+                }
+                if (-rc < best || (-rc == best && col < jn)) { best = -rc; jn = col; }
+            }
+            double dummy = 0.0;
+            batch_argmin_max(best, jn, dummy, red);
+            const double mx = -best;
+            last_price = mx;
+            if (lpx_is_optimal_max(mx)) { // :213-214
+                status = LPX_OPTIMAL;
+                break;
+            }
+            j = jn;
+        }
+        double sign = 1.0;
+        if (KIND == LPX_KIND_BOUNDED) {
+            const int vj = L.vstate[j];
+            if (vj == LPX_VS_UPPER) sign = -1.0;
+            else if (vj != LPX_VS_LOWER) { // special_solvers.py:331
+                status = LPX_NOT_NONBASIC;
+                last_j = j;
+                break;
+            }
+        }
+        // ---- d = B^-1 @ A[:, j] (primal_solvers.py:129): one lane per row, k ascending
+        double di = 0.0;
+        if (t < m) {
+            di = f32 ? (double)block_dot_g<float, 32>(L.Binv + t * ldb, 1, A + j, ldA, m)
+                     : block_dot_g<double, 32>(L.Binv + t * ldb, 1, A + j, ldA, m);
+            L.d[t] = di;
+        }
+        bool flip = false;
+        int lstate = LPX_VS_LOWER;
+        if (KIND == LPX_KIND_PRIMAL) { // ratio test :149-167, unboundedness :144-147
+            double th = (t < m) ? lpx_psd(L.xB[t], di, f32) : LPX_INF, dmax = (t < m) ? di : -LPX_INF;
+            int rr = (t < m) ? t : 0x7FFFFFFF;
+            batch_argmin_max(th, rr, dmax, red);
+            if (dmax <= 0.0) {
+                status = LPX_PRIMAL_UNBOUNDED;
+                last_j = j;
+                break;
+            }
+            r = rr;
+        } else if (KIND == LPX_KIND_BOUNDED) { // three-way ratio test, special_solvers.py:239-329
+            double g1 = LPX_INF, g2 = LPX_INF, dummy = 0.0;
+            int r1 = (t < m) ? t : 0x7FFFFFFF, r2 = r1;
+            if (t < m) {
+                const int bv = L.basis[t];
+                g1 = lpx_psd(L.xB[t] - L.lb[bv], sign * di, false);
+                g2 = lpx_psd(L.ub[bv] - L.xB[t], -sign * di, false);
+            }
+            batch_argmin_max(g1, r1, dummy, red);
+            batch_argmin_max(g2, r2, dummy, red);
+            const double g3 = L.ub[j] - L.lb[j];
+            const double delta = g1 < g2 ? g1 : g2;
+            if (delta == LPX_INF) { // :256-257 / :302-303
+                status = LPX_PRIMAL_UNBOUNDED;
+                last_j = j;
+                break;
+            }
+            if (g3 <= delta) flip = true; // :264-268 / :309-313
+            else if (g1 < g2) { r = r1; lstate = LPX_VS_LOWER; } // :271-277
+            else { r = r2; lstate = LPX_VS_UPPER; }              // :278-284
+        } else {
+            __syncthreads(); // L.d complete
+        }
+        int leaving = -1;
+        if (!flip) {
+            // ---- eta column (:236-244), copy of the old pivot row, rank-1 update of B^-1 (:247-249)
+            const double dr = L.d[r], xr = L.xB[r];
+            leaving = L.basis[r];
+            if (t < m) {
+                L.e[t] = (t == r) ? 1.0 / dr : (-di) / dr;
+                L.rowr[t] = L.Binv[r * ldb + t];
+            }
+            __syncthreads();
+            {
+                int i = t / m, k = t - i * m; // incremental (row, col) walk: no division in the loop
+                const int di2 = LPX_BLOCK / m, dk2 = LPX_BLOCK - di2 * m;
+                for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
+                    const double ei = L.e[i];
+                    double *p = &L.Binv[i * ldb + k];
+                    *p = (i == r) ? ei * L.rowr[k] : fma(ei, L.rowr[k], *p);
+                    i += di2; k += dk2;
+                    if (k >= m) { k -= m; i += 1; }
+                }
+            }
+            if (KIND != LPX_KIND_BOUNDED && t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]); // :251-253
+        }
+        if (t == 0) {
+            if (s.log && pivots < s.log_cap) {
+                int64_t *lg = s.log + pivots * 3;
+                lg[0] = flip ? -1 : r; lg[1] = j; lg[2] = leaving;
+            }
+            if (flip) {
+                L.vstate[j] = (sign > 0.0) ? LPX_VS_UPPER : LPX_VS_LOWER;
+            } else {
+                L.basis[r] = j; // :261
+                L.cb[r] = L.c[j];
+                L.vstate[leaving] = lstate;
+                L.vstate[j] = LPX_VS_BASIC;
+            }
+        }
+        pivots += 1;
+        last_j = j; last_r = flip ? -1 : r; last_leaving = leaving; last_flip = flip ? 1 : 0; last_lstate = lstate;
+        if (!flip) f32 = false;
+        __syncthreads();
+        if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs(); // special_solvers.py:341
+    }
+
+    // ---- state back to HBM
+    __syncthreads();
+    for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
+        const int i = idx / m, k = idx - i * m;
+        s.Binv[(int64_t)i * s.ldB + k] = L.Binv[i * ldb + k];
+    }
+    for (int col = t; col < n; col += LPX_BLOCK) s.var_state[col] = L.vstate[col];
+    if (t < m) {
+        s.basis[t] = L.basis[t];
+        s.xB[t] = L.xB[t];
+    }
+    if (a.x != nullptr) { // result assembly, primal_solvers.py:72-79 / special_solvers.py:201-206; cost in index order
+        for (int col = t; col < n; col += LPX_BLOCK) {
+            const int vs = L.vstate[col];
+            L.rc[col] = (KIND == LPX_KIND_BOUNDED && vs == LPX_VS_LOWER) ? L.lb[col]
+                        : (KIND == LPX_KIND_BOUNDED && vs == LPX_VS_UPPER) ? L.ub[col] : 0.0;
+        }
+        __syncthreads();
+        if (t < m) L.rc[L.basis[t]] = L.xB[t];
+        __syncthreads();
+        for (int col = t; col < n; col += LPX_BLOCK) a.x[(int64_t)blockIdx.x * n + col] = L.rc[col];
+    }
+    if (t == 0) {
+        if (a.cost != nullptr) {
+            double s1 = 0.0;
+            for (int col = 0; col < n; ++col) s1 = fma((double)L.c[col], L.rc[col], s1);
+            a.cost[blockIdx.x] = s1;
+        }
+        ctrl->status = status;
+        ctrl->f32_phase = f32 ? 1 : 0;
+        ctrl->counter = counter;
+        ctrl->pivots = pivots;
+        ctrl->enter_j = last_j;
+        ctrl->leave_r = last_r;
+        ctrl->leave_var = last_leaving;
+        ctrl->price_val = last_price;
+        ctrl->flip = last_flip;
+        ctrl->leave_state = last_lstate;
+    }
+}
+
+extern "C" int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind)
+{
+    if (m <= 0 || n <= 0) return 0;
+    return block_lds(m, n, kind, nullptr).bytes;
+}
+
+static int block_launch(const BlockArgs &a, int64_t batch, int64_t m, int64_t n, int kind, hipStream_t st)
+{
+    LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "kind must be primal, dual or bounded");
+    const int64_t bytes = block_lds(m, n, kind, nullptr).bytes;
+    if (bytes > LPX_BLOCK_LDS_MAX || m > 4096 || n > 65536) {
+        lpx_set_error("lpx_revised_solve_small: the state of a %lld x %lld LP needs %lld B of LDS, one CU has %d", (long long)m,
+                      (long long)n, (long long)bytes, LPX_BLOCK_LDS_MAX);
+        return LPX_E_SIZE;
+    }
+#define LPX_BLOCK_GO(K)                                                                                                      \
+    {                                                                                                                        \
+        LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); \
+        hipLaunchKernelGGL((k_block_solve<K>), dim3((unsigned)batch), dim3(LPX_BLOCK), (size_t)bytes, st, a);                \
+    }
+    if (kind == LPX_KIND_PRIMAL) LPX_BLOCK_GO(LPX_KIND_PRIMAL)
+    else if (kind == LPX_KIND_DUAL) LPX_BLOCK_GO(LPX_KIND_DUAL)
+    else LPX_BLOCK_GO(LPX_KIND_BOUNDED)
+#undef LPX_BLOCK_GO
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+extern "C" int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t maxiters, void *stream)
+{
+    LPX_REQUIRE(s != nullptr && s->m > 0 && s->n > 0 && maxiters >= 0, "bad state / sizes");
+    LPX_REQUIRE(s->A && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
+    LPX_REQUIRE(s->ldA >= s->n && s->ldB >= s->m, "leading dimensions too small");
+    LPX_REQUIRE(kind != LPX_KIND_BOUNDED || (s->lb && s->ub), "the bounded solver needs lb and ub");
+    BlockArgs a{};
+    a.single = *s;
+    a.states = nullptr;
+    a.maxiters = maxiters;
+    return block_launch(a, 1, s->m, s->n, kind, (hipStream_t)stream);
+}
+
+extern "C" int lpx_revised_solve_small_batch(const lpx_revised *dev_states, int64_t batch, int64_t m, int64_t n, int kind,
+                                             int64_t maxiters, double *x, double *cost, void *stream)
+{
+    LPX_REQUIRE(dev_states != nullptr && batch > 0 && m > 0 && n > 0 && maxiters >= 0, "bad arguments");
+    LPX_REQUIRE((x == nullptr) == (cost == nullptr), "x and cost come together");
+    BlockArgs a{};
+    a.states = dev_states;
+    a.maxiters = maxiters;
+    a.x = x;
+    a.cost = cost;
+    return block_launch(a, batch, m, n, kind, (hipStream_t)stream);
 }

@@ -1335,15 +1335,18 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_pd_theta(PdArgs a)
     }
 }
 __global__ __launch_bounds__(LPX_BLOCK) void k_pd_axpy(Partials P, int64_t np, const double *yrp, double *y, int64_t m,
-                                                      double *out)
+                                                      double *out, const double *gate)
 {
     __shared__ BlockRed red;
     const double th = combine_min(P.v0, np, red);
     const double um = combine_max(P.v1, np, red);
+    const double g = gate ? *gate : 1.0; // cost of the restricted primal: the dual step exists only while it is > 0 (:427)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[0] = th;
         out[1] = um;
+        if (gate) out[2] = g;
     }
+    if (!(g > 0.0)) return; // complementary slackness attained (:445-447): y stays
     if (um <= 0.0) return; // DualIsUnboundedError, special_solvers.py:435-436
     const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
     if (i < m) y[i] = y[i] + th * yrp[i]; // :444  (numpy: theta * y_rp, then +=; two roundings)
@@ -1380,7 +1383,7 @@ extern "C" int lpx_pd_admissible(const lpx_revised *s, const double *y, const do
 }
 
 extern "C" int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c64, const double *v, int64_t n_orig,
-                                double *out, void *stream)
+                                double *out, const double *cost_gate, void *stream)
 {
     int rc = check_revised(s);
     if (rc) return rc;
@@ -1407,7 +1410,7 @@ extern "C" int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c
     const int64_t nb = lpx_cdiv(n_orig > s->m ? n_orig : s->m, LPX_BLOCK);
     hipLaunchKernelGGL(k_pd_theta, dim3((unsigned)nb), dim3(LPX_BLOCK), 0, st, p);
     hipLaunchKernelGGL(k_pd_axpy, dim3((unsigned)lpx_cdiv(s->m, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, w.price, nb,
-                       (const double *)w.y, y, s->m, out);
+                       (const double *)w.y, y, s->m, out, cost_gate);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

@@ -6,6 +6,7 @@ per chunk of iterations -- the only host round trip of the loop (north star: "no
 beyond a scalar status flag").
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -81,12 +82,30 @@ class RevisedEngine:
     #: opt-in: re-invert from scratch (lpx_revised_reinvert_f64) every this many pivots inside run(); None = never
     reinvert_every = None
 
+    #: a lone small LP is launch-bound on the multi-kernel chain (~40 us per iteration whatever its size): when the state
+    #: fits one CU's LDS the whole solve() call is ONE launch (lpx_revised_solve_small); LPX_SMALL_SOLVE=0 disables
+    SMALL_SOLVE = os.environ.get("LPX_SMALL_SOLVE", "1") != "0"
+    SMALL_LDS_MAX = 158 * 1024
+
+    #: rows up to which the one-launch kernel beats the chain (tools/small_solve_bench.py on MI355X: per iteration at
+    #: m = 64 / 128 -- dual 10 / 21 us against the chain's 28 / 28; bounded, whose x_B is recomputed from scratch through
+    #: an n-long chain every iteration, 30 / 55 us against 42 / 41)
+    SMALL_MAX_ROWS = {_lib.KIND_PRIMAL: 128, _lib.KIND_DUAL: 128, _lib.KIND_BOUNDED: 96}
+
+    def fits_small(self, kind):
+        return (self.SMALL_SOLVE and not self.naive and not self.refine_every and not self.reinvert_every
+                and kind in self.SMALL_MAX_ROWS and self.m <= self.SMALL_MAX_ROWS[kind]
+                and self.lib.lpx_revised_small_lds_bytes(self.m, self.n, kind) <= self.SMALL_LDS_MAX)
+
     def run(self, kind, maxiters):
         """One ``solve(maxiters)`` call of the reference: returns the control block after the loop ended."""
         st = stream_ptr()
         last_refine = None
         last_reinvert = None
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
+        if self.fits_small(kind):
+            _lib.check(self.lib.lpx_revised_solve_small(C.byref(self.s), kind, int(maxiters), st))
+            return self.read_ctrl()
         left = int(maxiters)
         ctrl = None
         first = True

@@ -170,7 +170,7 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
         y = to_device(y0.astype(np.float64))
         c64 = to_device(np.asarray(self.c, dtype=np.float64))
         v = torch.zeros(n, dtype=torch.float64, device="cuda")
-        out = torch.zeros(2, dtype=torch.float64, device="cuda")
+        out = torch.zeros(3, dtype=torch.float64, device="cuda")
         eye = torch.eye(m, dtype=torch.float64, device="cuda")
         b_dev = to_device(b_rp.astype(np.float64))
         art_dev = to_device(art_basis.astype(np.int64))
@@ -179,6 +179,7 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
 
         x_rp = None
         inner_basis = art_basis
+        solved = False
         while self.counter < maxiters1:
             self.counter += 1
             _lib.check(lib.lpx_pd_admissible(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, v.data_ptr(), st))  # :405
@@ -203,18 +204,23 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
                 raise PrimalIsUnboundedError
             if self._LOG_CAP:
                 self.inner_pivot_logs.append(eng.host_log(ctrl.pivots))
-            x_rp, cost_rp = eng.expand()
-            inner_basis = eng.host_basis()
-            if cost_rp > 0.0:  # :427-444
-                _lib.check(lib.lpx_pd_dual_step(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), v.data_ptr(), n,
-                                                out.data_ptr(), st))
-                theta, umax = out.cpu().numpy()
+            # x, cost of the restricted primal (:72-79) and the dual step (:427-444), gated on the device by that cost:
+            # one read of (theta, umax, cost) is the only other host round trip of an outer iteration
+            _lib.check(lib.lpx_revised_expand(C.byref(eng.s), eng.x.data_ptr(), eng.cost.data_ptr(), st))
+            _lib.check(lib.lpx_pd_dual_step(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), v.data_ptr(), n,
+                                            out.data_ptr(), eng.cost.data_ptr(), st))
+            theta, umax, cost_rp = out.cpu().numpy()
+            solved = True
+            if cost_rp > 0.0:
                 if umax <= 0:
                     raise DualIsUnboundedError  # :435-436
             else:
                 self.optimum = True
                 break  # complementary slackness attained
 
+        if solved:
+            x_rp = eng.x.cpu().numpy()
+            inner_basis = eng.host_basis()
         x = np.zeros(n) if x_rp is None else x_rp[:n].copy()
         basis = inner_basis[inner_basis < n]
         cost = np.dot(self.c, x)  # :464

@@ -66,6 +66,60 @@ def test_base_solvers_match_reference(cs):
         assert np.array_equal(res.basis, cs["optimal_basis"])
 
 
+SMALL = [cs for cs in BASE if "Naive" not in cs["solver"] and cs.get("m", 3) <= 64 and not cs["ref"]["exception"]]
+
+
+@pytest.mark.parametrize("cs", SMALL[::3], ids=case_id)
+def test_multi_kernel_chain_on_small_problems(cs, monkeypatch):
+    """Small LPs run as one launch by default (lpx_revised_solve_small); the multi-kernel chain that the large problems
+    use must take the same pivots on them (LPX_SMALL_SOLVE=0)."""
+    import linprog_amd.engine as engine
+
+    monkeypatch.setattr(engine.RevisedEngine, "SMALL_SOLVE", False)
+    ref = cs["ref"]
+    s = logged(solver_class(cs["solver"]), cap=max(16, len(ref["pivots"]) + 1))(*problem_of(cs))
+    assert not s._engine.fits_small(s._device_kind())
+    res = s.solve(cs.get("maxiters", 100))
+    assert s.pivot_log().tolist() == ref["pivots"] and res.iters == ref["iters"] and res.basis.tolist() == ref["basis"]
+    assert_close(res.cost, ref["cost"], "cost")
+
+
+@pytest.mark.parametrize("kind,m,n,seed", [("primal", 64, 128, 3), ("primal", 37, 100, 4), ("primal", 128, 256, 5),
+                                           ("dual", 64, 128, 6), ("dual", 100, 210, 7), ("bounded", 64, 128, 2),
+                                           ("bounded", 128, 256, 3), ("bounded", 33, 67, 4)])
+def test_one_launch_small_solve_bit_identical_to_oracle(kind, m, n, seed, monkeypatch):
+    """lpx_revised_solve_small: the whole solve() call in one launch, B^-1 in LDS.  Dot products run in the oracle's
+    order, so the pivot log, B^-1, x_B, basis and the per-variable states are bit-identical to the oracle's loops, also
+    when the solve is cut into re-entrant pieces (state written back and reloaded between calls)."""
+    from linprog_amd.dual_solvers import DualRevisedSimplexSolver
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from linprog_amd.special_solvers import BoundedVariablePrimalSimplexSolver
+    from oracle import oracle as O
+    import linprog_amd.engine as engine
+
+    monkeypatch.setattr(engine.RevisedEngine, "SMALL_MAX_ROWS", {0: 4096, 1: 4096, 2: 4096})  # every shape that fits LDS
+    if kind == "bounded":
+        args = gen.gen_box(m, n, seed)
+        s = logged(BoundedVariablePrimalSimplexSolver)(*args)
+        o = O.OracleBounded(*args)
+    else:
+        args = (gen.gen_primal if kind == "primal" else gen.gen_dual)(m, n, seed)
+        s = logged(PrimalRevisedSimplexSolver if kind == "primal" else DualRevisedSimplexSolver)(*args)
+        o = O.OracleRevised(*args, kind=kind)
+    assert s._engine.fits_small(s._device_kind())
+    for k in (1, 2, 7, 100000):
+        res = s.solve(k)
+        want = o.solve(k)
+        eng = s._engine
+        assert s.pivot_log().tolist() == want.log.tolist()
+        assert res.iters == want.iters and res.basis.tolist() == want.basis.tolist()
+        assert np.array_equal(eng.host_Binv(), o.Binv) and np.array_equal(eng.host_xB(), o.xB)
+        assert np.array_equal(res.x, want.x)
+        if kind == "bounded":
+            assert np.array_equal(eng.host_var_state(), want.var_state)
+    assert res.optimum
+
+
 @pytest.mark.parametrize("name", ["PrimalRevisedSimplexSolver", "PrimalNaiveSimplexSolver"])
 def test_blands_sequence_reentrant(name):
     """tests/test_primal_base_solvers.py:24-34 of the reference."""

@@ -591,3 +591,56 @@ def test_batched_tableau_kernel_from_a_general_starting_basis(m, n):
             assert abs(res[i].cost - r1.cost) <= 1e-13 * max(1.0, abs(r1.cost))  # tree dot there, sequential here
             assert res[i].optimum == (ref.status == O.OPTIMAL)
             assert np.allclose(res[i].x, ref.x, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,count", [(16, 32, 40), (64, 128, 24), (33, 67, 9), (128, 256, 6)])
+def test_batched_bounded_bit_identical_to_oracle(m, n, count):
+    """BatchedBoundedSolver (one workgroup per LP, lpx_revised_solve_small_batch): step logs (basis changes and bound
+    flips), x, x_B-derived basis, per-variable bound states and iteration counts bit-identical to the oracle's bounded
+    loop LP by LP -- whose own logs are pinned to the reference's by tests/golden/bounded.json -- and the golden cases
+    themselves (seeds 0, 1) reproduce the reference's steps."""
+    from linprog_amd import _lib
+    from linprog_amd.batched import BatchedBoundedSolver
+    from oracle import oracle as O
+
+    probs = [gen.gen_box(m, n, s) for s in range(count)]
+    c, A, b, lb, ub, basis = [np.stack([p[k] for p in probs]) for k in range(6)]
+    vs = np.full((count, n), _lib.VS_LOWER, dtype=np.int32)  # gen_box: every structural variable starts at its lower bound
+    s = BatchedBoundedSolver(c, A, b, lb, ub, basis, vs, log_cap=2048)
+    res = s.solve(100000)
+    logs = s.pivot_logs()
+    golden = {cs["seed"]: cs["ref"] for cs in load("bounded.json") if cs["m"] == m and cs["n"] == n}
+    for i, p in enumerate(probs):
+        o = O.OracleBounded(*p).solve(100000)
+        assert res[i].optimum and res[i].iters == o.iters and res[i].basis.tolist() == o.basis.tolist()
+        assert logs[i].tolist() == o.log.tolist()
+        assert np.array_equal(res[i].x, o.x) and np.array_equal(s.raw["var_state"][i], o.var_state)
+        assert_close(res[i].cost, o.cost, "cost")
+        if i in golden:
+            ref = golden[i]
+            assert [list(map(int, e)) for e in logs[i].tolist()] == [e[:3] for e in ref["steps"]]
+            assert res[i].iters == ref["iters_total"]
+            assert_close(res[i].x, ref["x"], "x")
+            assert_close(res[i].cost, ref["cost"], "cost")
+
+
+def test_batched_bounded_reentrant_and_upper_bound_start():
+    """Calls of a few iterations each continue from the state the previous one left (solve(maxiters=1) repeated is how
+    the goldens were traced), and a start with variables at their UPPER bound prices them with the opposite sign."""
+    from linprog_amd import _lib
+    from linprog_amd.batched import BatchedBoundedSolver
+    from oracle import oracle as O
+
+    m, n, count = 24, 48, 8
+    probs = [gen.gen_box(m, n, 100 + s) for s in range(count)]
+    c, A, b, lb, ub, basis = [np.stack([p[k] for p in probs]) for k in range(6)]
+    vs = np.full((count, n), _lib.VS_LOWER, dtype=np.int32)
+    vs[:, 1:5] = _lib.VS_UPPER
+    s = BatchedBoundedSolver(c, A, b, lb, ub, basis, vs)
+    oracles = [O.OracleBounded(p[0], p[1], p[2], p[3], p[4], p[5], [0] + list(range(5, n - m)), [1, 2, 3, 4]) for p in probs]
+    for k in (1, 3, 2, 100000):
+        res = s.solve(k)
+        for i, o in enumerate(oracles):
+            w = o.solve(k)
+            assert res[i].iters == w.iters and res[i].basis.tolist() == w.basis.tolist() and np.array_equal(res[i].x, w.x)
+            assert bool(res[i].optimum) == (w.status == O.OPTIMAL)
