@@ -55,26 +55,44 @@ class ProposalExchange:
         self.recvbufs = [torch.zeros(self.msg * self.nranks, dtype=torch.float64, device=device) for _ in range(2)]
         self.sendbuf, self.recvbuf = self.sendbufs[0], self.recvbufs[0]
         self.staged = dist.get_backend(group) == "gloo" and self.sendbuf.is_cuda
+        self.side = None
+        if self.staged:
+            self.pinned = [torch.zeros(self.msg * self.nranks, dtype=torch.float64).pin_memory() for _ in range(2)]
 
     def all_gather(self, slot=0):
         self.wait(self.all_gather_async(slot))
         return self.recvbufs[slot]
 
     def all_gather_async(self, slot):
-        """Start the all-gather of slot `slot`; returns a handle for wait() (None: already complete).  With the nccl
-        backend the collective is ordered after the work already enqueued on the current stream and runs beside what
-        is enqueued next; wait() makes the current stream (not the host) wait for it."""
+        """Start the all-gather of slot `slot`; returns a handle for wait().  With the nccl backend the collective is
+        ordered after the work already enqueued on the current stream and runs beside what is enqueued next; wait() makes
+        the current stream (not the host) wait for it.  The staged gloo path (CPU rehearsal with device buffers) keeps the
+        same discipline on a side stream: the copy of the gathered proposals into the receive slot is ordered after the
+        kernels that wrote the send slot, runs beside the update kernel that the caller launches next, and the current
+        stream waits for its event -- so the two-slot ordering is exercised without a multi-GPU node."""
         send, recv = self.sendbufs[slot], self.recvbufs[slot]
+        torch = self.torch
         if self.staged:
-            host = self.torch.zeros(self.msg * self.nranks, dtype=self.torch.float64)
-            self.dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
-            recv.copy_(host)
-            return None
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                host = torch.zeros(self.msg * self.nranks, dtype=torch.float64)
+                self.dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+                self.pinned[slot].copy_(host)
+                recv.copy_(self.pinned[slot], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            return done
         return self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
 
-    @staticmethod
-    def wait(work):
-        if work is not None:
+    def wait(self, work):
+        if work is None:
+            return
+        if self.staged:
+            self.torch.cuda.current_stream().wait_event(work)
+        else:
             work.wait()
 
 
