@@ -219,6 +219,19 @@ int lpx_pd_admissible(const lpx_revised *s, const double *y, const double *c64, 
 int lpx_pd_dual_step(const lpx_revised *s, double *y, const double *c64, const double *v, int64_t n_orig,
                      double *out, const double *cost_gate, void *stream);
 
+/* ------------------------------------------------------------------------ problem construction on the device */
+/* ProblemPreprocessingUtils.canonical_form_to_standard_form + add_variables_bounds_to_coefficient_matrix +
+ * preprocess_problem (preprocessing.py:6-69), and the artificial block of PhaseOneSimplexSolver (special_solvers.py:48-52),
+ * as ONE kernel that writes the standard-form matrix into HBM instead of vstack / hstack chains on the host:
+ * rows = me equalities (A x = b), mi inequalities (G x <= h, one slack column each), nb bound rows (variable bound_var[t],
+ * slack sign bound_sign[t] = -1 for x - s = lb / +1 for x + s = ub, right-hand side bound_val[t]; lower bounds first);
+ * columns = nx structural + mi + nb slack + na artificial (na = 0 or rows).  Rows with a negative right-hand side are
+ * negated (:11-13) except in the artificial block, which the reference appends afterwards.  A is me x nx, G is mi x nx,
+ * out is rows x ld (float32), out_b the normalised right-hand side. */
+int lpx_build_standard_form(int64_t me, int64_t mi, int64_t nx, int64_t nb, int64_t na, const float *A, const float *b,
+                            const float *G, const float *h, const int64_t *bound_var, const float *bound_sign,
+                            const float *bound_val, float *out, int64_t ld, float *out_b, void *stream);
+
 /* ----------------------------------------------------------------------------- tableau-form solver loop */
 int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
 /* `iters` primal iterations on an unpartitioned tableau (same rules as LPX_KIND_PRIMAL). */

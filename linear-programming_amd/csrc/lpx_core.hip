@@ -1246,6 +1246,71 @@ extern "C" int lpx_revised_reduced_costs(const lpx_revised *s, int bounded, doub
     return LPX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Problem construction on the device (preprocessing.py:6-69, special_solvers.py:48-52): the standard-form matrix of
+//   min c x  s.t.  A x = b (me rows),  G x <= h (mi rows),  bounds on nb variables
+// assembled directly in HBM instead of by vstack / hstack chains on the host:
+//        nx cols   mi cols   nb cols   na cols
+//      [   A         0         0        I    ]   me rows
+//      [   G         I         0        I    ]   mi rows   canonical_form_to_standard_form, :17-28
+//      [   E         0       diag(s)    I    ]   nb rows   add_variables_bounds_to_coefficient_matrix, :30-69:
+//                                                          x_i - s = lb_i (s = -1) or x_i + s = ub_i (s = +1), one row and
+//                                                          one column per finite bound, lower bounds first
+// with every row whose right-hand side is negative negated afterwards (preprocess_problem, :6-15); the last block
+// (na = rows or 0) is the artificial identity of the phase-one problem, appended AFTER the sign normalisation as the
+// reference does (special_solvers.py:48-52), so it stays +I.  One thread per element of the output.
+// ---------------------------------------------------------------------------------------------------------
+struct StdFormArgs {
+    int64_t me, mi, nx, nb, na, ld;
+    const float *A, *b, *G, *h;
+    const int64_t *bound_var;
+    const float *bound_sign, *bound_val;
+    float *out, *out_b;
+};
+__global__ __launch_bounds__(LPX_BLOCK) void k_build_standard_form(StdFormArgs a)
+{
+    const int64_t rows = a.me + a.mi + a.nb, core = a.nx + a.mi + a.nb, cols = core + a.na;
+    const int64_t idx = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int64_t i = idx / cols, j = idx - i * cols;
+    float rhs, v = 0.f;
+    if (i < a.me) {
+        rhs = a.b[i];
+        if (j < a.nx) v = a.A[i * a.nx + j];
+    } else if (i < a.me + a.mi) {
+        const int64_t g = i - a.me;
+        rhs = a.h[g];
+        if (j < a.nx) v = a.G[g * a.nx + j];
+        else if (j - a.nx == g) v = 1.f;
+    } else {
+        const int64_t t = i - a.me - a.mi;
+        rhs = a.bound_val[t];
+        if (j < a.nx) v = (j == a.bound_var[t]) ? 1.f : 0.f;
+        else if (j - a.nx - a.mi == t) v = a.bound_sign[t];
+    }
+    const bool flip = rhs < 0.f; // preprocessing.py:11-13
+    if (j < core) v = flip ? -v : v;
+    else v = (j - core == i) ? 1.f : 0.f; // artificial block, added after the flips
+    a.out[i * a.ld + j] = v;
+    if (j == 0) a.out_b[i] = flip ? -rhs : rhs;
+}
+extern "C" int lpx_build_standard_form(int64_t me, int64_t mi, int64_t nx, int64_t nb, int64_t na, const float *A, const float *b,
+                                       const float *G, const float *h, const int64_t *bound_var, const float *bound_sign,
+                                       const float *bound_val, float *out, int64_t ld, float *out_b, void *stream)
+{
+    const int64_t rows = me + mi + nb, cols = nx + mi + nb + na;
+    LPX_REQUIRE(me >= 0 && mi >= 0 && nb >= 0 && nx > 0 && rows > 0, "bad sizes");
+    LPX_REQUIRE(na == 0 || na == rows, "the artificial block has one column per row or none");
+    LPX_REQUIRE((me == 0 || (A && b)) && (mi == 0 || (G && h)) && (nb == 0 || (bound_var && bound_sign && bound_val)),
+                "null input for a non-empty block");
+    LPX_REQUIRE(out && out_b && ld >= cols, "null output / ld < columns");
+    StdFormArgs a{me, mi, nx, nb, na, ld, A, b, G, h, bound_var, bound_sign, bound_val, out, out_b};
+    hipLaunchKernelGGL(k_build_standard_form, dim3((unsigned)lpx_cdiv(rows * cols, LPX_BLOCK)), dim3(LPX_BLOCK), 0,
+                       (hipStream_t)stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 // One row of the tableau B^-1 A (special_solvers.py:69-71: PhaseOneSimplexSolver looks for a positive entry in the row of
 // a basic artificial variable to pivot it out; the reference forms the whole m x n product for it).  A thread per column,
 // the weights B^-1[row, :] staged in LDS in chunks, fma in row order.  Independent of the loop's status word.

@@ -25,12 +25,19 @@ class RevisedEngine:
         torch = torch_cuda()
         self.lib = _lib.load()
         self.torch = torch
-        m, n = A32.shape
+        m, n = A32.shape  # a host array, or a preprocessing.DeviceProblem whose matrix is in HBM already
         self.m, self.n = m, n
         # B^-1 is the matrix K1 streams: 4-KiB-aligned rows once it is large (see tableau.row_alignment)
         pad = lambda cols, unit: roundup(cols, 4096 // unit if cols * unit >= 32768 else (128 // unit if cols * unit >= 1024 else 16 // unit))
         self.ldA, self.ldAt, self.ldB = pad(n, 4), pad(m, 4), pad(m, 8)
-        self.A = to_device_2d(A32.astype(np.float32, copy=False), self.ldA, torch.float32)
+        if hasattr(A32, "A_dev"):
+            if A32.A_dev.shape[1] == self.ldA:
+                self.A = A32.A_dev
+            else:  # re-pitch on the device
+                self.A = torch.zeros((m, self.ldA), dtype=torch.float32, device="cuda")
+                self.A[:, :n].copy_(A32.A_dev[:, :n])
+        else:
+            self.A = to_device_2d(A32.astype(np.float32, copy=False), self.ldA, torch.float32)
         self.At = torch.zeros((n, self.ldAt), dtype=torch.float32, device="cuda")
         self.At[:, :m].copy_(self.A[:, :n].t())
         self.b = to_device(b32.astype(np.float32, copy=False))

@@ -12,7 +12,7 @@ from . import _lib
 from .data_classes import LinProgResult
 from .engine import RevisedEngine
 from .exceptions import BasisIsPrimalInfeasibleError, PrimalIsUnboundedError
-from .preprocessing import ProblemPreprocessingUtils
+from .preprocessing import DeviceProblem, ProblemPreprocessingUtils
 
 
 def signed_identity_diagonal(B):
@@ -23,6 +23,14 @@ def signed_identity_diagonal(B):
     if np.count_nonzero(B) == m and np.all(np.abs(d) == 1.0):
         return d.astype(np.float32)
     return None
+
+
+def _initial_inverse_device(prob, basis):
+    """``_initial_inverse`` for a problem whose matrix is on the device: the artificial basis of phase one is the identity
+    by construction; any other basis costs an m x m download of its columns for the reference's float32 LAPACK inverse."""
+    if prob.basis_is_artificial_identity(basis):
+        return np.eye(prob.m, dtype=np.float32), prob.b32.copy()
+    return _initial_inverse(prob.columns(basis), np.arange(prob.m), prob.b32)
 
 
 def _initial_inverse(A32, basis, b32):
@@ -53,17 +61,36 @@ class PrimalNaiveSimplexSolver:
     _LOG_CAP = 0
 
     def __init__(self, c, A, b, basis):
-        self.c, self.A, self.b = self._preprocess_problem(c, A, b)
-        self.m, self.n = self.A.shape
+        """``A`` may be a ``preprocessing.DeviceProblem`` (matrix already in HBM, preprocessed): c and b are then taken
+        from it and ``self.A`` downloads the matrix only if somebody reads it."""
+        self._dev_problem = A if isinstance(A, DeviceProblem) else None
+        if self._dev_problem is not None:
+            self.c, self.b = A.c32, A.b32
+            self.m, self.n = A.shape
+        else:
+            self.c, self._A, self.b = self._preprocess_problem(c, A, b)
+            self.m, self.n = self._A.shape
         self.row_offset = 1
         self.col_offset = 1
         self.basis = np.array(basis).astype(int)
-        inv32, bfs32 = _initial_inverse(self.A, self.basis, self.b)
+        if self._dev_problem is not None:
+            inv32, bfs32 = _initial_inverse_device(A, self.basis)
+        else:
+            inv32, bfs32 = _initial_inverse(self._A, self.basis, self.b)
         self.counter = None
         self.optimum = None
         self._check_basis_feasibility(inv32, bfs32)
-        self._engine = RevisedEngine(self.c, self.A, self.b, self.basis, inv32, bfs32, log_cap=self._LOG_CAP,
-                                     naive=self._NAIVE)
+        self._engine = RevisedEngine(self.c, A if self._dev_problem is not None else self._A, self.b, self.basis, inv32,
+                                     bfs32, log_cap=self._LOG_CAP, naive=self._NAIVE)
+
+    @property
+    def A(self):
+        return self._dev_problem.host() if getattr(self, "_dev_problem", None) is not None else self._A
+
+    @A.setter
+    def A(self, value):
+        self._dev_problem = None
+        self._A = value
 
     # ------------------------------------------------------------------ constructor helpers
     def _preprocess_problem(self, c, A, b):

@@ -10,42 +10,42 @@ from .special_solvers import PhaseOneSimplexSolver
 
 
 class SimplexSolver(PrimalRevisedSimplexSolver):
-    """min c'x  s.t.  Ax = b, Gx <= h, lb <= x <= ub  (simplex.py:11-77)."""
+    """min c'x  s.t.  Ax = b, Gx <= h, lb <= x <= ub  (simplex.py:11-77).
+
+    The standard form (slack columns, simplex.py:35-62 / preprocessing.py:17-28), the bound rows (:30-69) and the
+    phase-one artificial block (special_solvers.py:48-52) are assembled on the device (``standard_form_on_device``);
+    ``self.A`` downloads the standard-form matrix only when read."""
 
     def __init__(self, c, A=None, b=None, G=None, h=None, lb=None, ub=None):
         have_eq = A is not None and b is not None
         have_ineq = G is not None and h is not None
-        self.num_slack_vars = 0 if G is None else np.asarray(G).shape[0]
-        if have_eq and not have_ineq:
-            A_, b_ = np.array(A), np.array(b)
-        elif have_ineq and not have_eq:
-            _, A_, b_ = ProblemPreprocessingUtils.canonical_form_to_standard_form(c, G, h)
-        elif have_eq and have_ineq:
-            # the reference raises TypeError here (np.zeros called with two positional sizes, simplex.py:57);
-            # the intended stacking is [[A 0], [G I]]
-            _, G_, h_ = ProblemPreprocessingUtils.canonical_form_to_standard_form(c, G, h)
-            A_ = np.vstack([np.hstack([np.array(A), np.zeros((np.asarray(A).shape[0], self.num_slack_vars))]), G_])
-            b_ = np.concatenate([np.array(b), np.array(h_)])
-        else:
+        if not (have_eq or have_ineq):
             raise ValueError("Input polyhedral misspcified.")
-        c_ = np.concatenate([np.array(c), np.zeros(self.num_slack_vars)])
-        nstruct = A_.shape[1] - self.num_slack_vars
+        self.num_slack_vars = 0 if G is None else np.asarray(G).shape[0]
+        # (when both are given the reference raises TypeError: np.zeros called with two positional sizes, simplex.py:57;
+        # the intended stacking [[A 0], [G I]] is what is built here)
+        self._inputs = (np.array(c), A if have_eq else None, b if have_eq else None, G if have_ineq else None,
+                        h if have_ineq else None)
+        self._dev_problem = ProblemPreprocessingUtils.standard_form_on_device(*self._inputs)
+        self.c, self.b = self._dev_problem.c32, self._dev_problem.b32
+        nstruct = self._dev_problem.n - self.num_slack_vars
         if lb is None:
             lb = np.repeat(0, nstruct)
         self.lb = np.concatenate([np.array(lb), np.repeat(0, self.num_slack_vars)])
         if ub is None:
             ub = np.repeat(np.inf, nstruct)
         self.ub = np.concatenate([np.array(ub), np.repeat(np.inf, self.num_slack_vars)])
-        self.c, self.A, self.b = ProblemPreprocessingUtils.preprocess_problem(c_, A_, b_)
-        self.num_vars = self.A.shape[1]
+        self.num_vars = self._dev_problem.n
 
     def solve(self, maxiters1: int = 100, maxiters2: int = 100):
         """Phase one for a basis, then the primal loop from it (simplex.py:79-102)."""
-        c1, A1, b1 = ProblemPreprocessingUtils.add_variables_bounds_to_coefficient_matrix(
-            self.c, self.A, self.b, self.lb, self.ub)
-        phase_one = PhaseOneSimplexSolver(c1, A1, b1)
+        c, A, b, G, h = self._inputs
+        nstruct = self.num_vars - self.num_slack_vars
+        aux = ProblemPreprocessingUtils.standard_form_on_device(c, A, b, G, h, self.lb[:nstruct], self.ub[:nstruct],
+                                                                artificials=True)
+        phase_one = PhaseOneSimplexSolver(None, aux, None)
         phase_one.solve(maxiters=maxiters1)
-        solver = PrimalRevisedSimplexSolver(c1, A1, b1, phase_one.basis)
+        solver = PrimalRevisedSimplexSolver(None, aux.core, None, phase_one.basis)
         res = solver.solve(maxiters=maxiters2)
         res.x = res.x[: self.num_vars - self.num_slack_vars]  # drop slack variables
         res.basis = None  # not interpretable without them (simplex.py:101)

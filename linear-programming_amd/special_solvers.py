@@ -14,28 +14,42 @@ from .data_classes import LinProgResult
 from .device import stream_ptr, to_device, torch_cuda
 from .engine import RevisedEngine
 from .exceptions import DualIsUnboundedError, PrimalIsInfeasibleError, PrimalIsUnboundedError
-from .preprocessing import ProblemPreprocessingUtils
+from .preprocessing import DeviceProblem, ProblemPreprocessingUtils
 from .dual_solvers import DualRevisedSimplexSolver
 from .primal_solvers import PrimalRevisedSimplexSolver, _initial_inverse
 from .utils import get_bounds_on_bfs
 
 
 class PhaseOneSimplexSolver(PrimalRevisedSimplexSolver):
-    """Phase I of the two-phase method (special_solvers.py:11-91): finds a starting basis, sets ``.basis``."""
+    """Phase I of the two-phase method (special_solvers.py:11-91): finds a starting basis, sets ``.basis``.
+
+    ``A`` may be a ``preprocessing.DeviceProblem`` built with ``artificials=True``: the auxiliary problem ``[A | I]`` is
+    then in HBM already (one kernel, no host hstack) and phase one never sees the matrix on the host."""
 
     def __init__(self, c, A, b):
-        self.c, self.A, self.b = self._preprocess_problem(c, A, b)
-        self.m, self.n = self.A.shape
+        if isinstance(A, DeviceProblem):
+            assert A.artificial_from is not None, "phase one needs the artificial block (standard_form_on_device(artificials=True))"
+            self._aux = A
+            self._dev_problem = A.core
+            self.c, self.b = A.core.c32, A.core.b32
+            self.m, self.n = A.core.shape
+        else:
+            self._aux = None
+            self.c, self.A, self.b = self._preprocess_problem(c, A, b)
+            self.m, self.n = self.A.shape
         self.row_offset = 1
         self.col_offset = 1
         self.basis = None
 
     def solve(self, maxiters: int = 100):
-        c = np.hstack([np.zeros(self.n), np.ones(self.m)])
-        A = np.hstack([self.A, np.eye(self.m)])
-        b = np.array(self.b)
         basis = np.arange(self.n, self.n + self.m)
-        solver = PrimalRevisedSimplexSolver(c, A, b, basis)  # the hot path: device primal loop
+        if self._aux is not None:
+            solver = PrimalRevisedSimplexSolver(None, self._aux, None, basis)  # the hot path: device primal loop
+        else:
+            c = np.hstack([np.zeros(self.n), np.ones(self.m)])
+            A = np.hstack([self.A, np.eye(self.m)])
+            b = np.array(self.b)
+            solver = PrimalRevisedSimplexSolver(c, A, b, basis)  # the hot path: device primal loop
         res = solver.solve(maxiters)
 
         if res.cost > 0:  # special_solvers.py:55-59
@@ -60,7 +74,10 @@ class PhaseOneSimplexSolver(PrimalRevisedSimplexSolver):
         if res.basis.max() >= self.n:
             # remaining artificials mark redundant equations (special_solvers.py:82-89, `<=` kept as is)
             keep = res.basis <= self.n
-            self.A = self.A[keep]
+            if self._dev_problem is not None:
+                self._dev_problem = self._dev_problem.select_rows(keep)
+            else:
+                self.A = self.A[keep]
             self.b = self.b[keep]
             self.m = keep.sum()
             res.basis = res.basis[keep]

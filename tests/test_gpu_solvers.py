@@ -285,6 +285,54 @@ def test_tableau_row_entry_point_and_artificial_drive_out():
         assert p1.basis.tolist() == want_basis and int(p1.m) == want_m and p1.A.shape[0] == want_m
 
 
+def test_standard_form_on_device_equals_the_host_helpers():
+    """lpx_build_standard_form (slack columns, bound rows, sign normalisation, phase-one artificial block in one kernel)
+    against the host restatements of preprocessing.py:6-69 applied in the reference's order, entry for entry."""
+    import json
+    import os
+
+    from linprog_amd.preprocessing import ProblemPreprocessingUtils as P
+    from tests._util import ROOT
+
+    rng = np.random.default_rng(3)
+    cases = []
+    cs = json.load(open(os.path.join(ROOT, "tests", "golden", "diet.json")))["cases"][0]
+    a = {k: np.array(v, dtype=float) for k, v in cs["arrays"].items()}
+    cases.append((a["c"], None, None, a["G"], a["h"], a["lb"], a["ub"]))
+    for me, mi, nx in ((3, 0, 7), (0, 5, 4), (4, 6, 9)):
+        c = rng.standard_normal(nx)
+        A = rng.standard_normal((me, nx)) if me else None
+        b = rng.standard_normal(me) if me else None  # negative entries: rows get flipped
+        G = rng.standard_normal((mi, nx)) if mi else None
+        h = rng.standard_normal(mi) if mi else None
+        lb = np.where(rng.random(nx) < 0.4, rng.standard_normal(nx), 0.0)
+        ub = np.where(rng.random(nx) < 0.4, 3.0 + rng.random(nx), np.inf)
+        cases.append((c, A, b, G, h, lb, ub))
+    for c, A, b, G, h, lb, ub in cases:
+        mi = 0 if G is None else G.shape[0]
+        # host: the reference's sequence (simplex.py:35-77, then :83-85)
+        if G is not None and A is None:
+            c0, A0, b0 = P.canonical_form_to_standard_form(c, G, h)
+        elif G is None:
+            c0, A0, b0 = P.preprocess_problem(c, A, b)
+        else:
+            _, G_, h_ = P.canonical_form_to_standard_form(c, G, h)
+            c0, A0, b0 = P.preprocess_problem(np.concatenate([c, np.zeros(mi)]),
+                                              np.vstack([np.hstack([A, np.zeros((A.shape[0], mi))]), G_]), np.concatenate([b, h_]))
+        lbx, ubx = np.concatenate([lb, np.zeros(mi)]), np.concatenate([ub, np.full(mi, np.inf)])
+        c1, A1, b1 = P.add_variables_bounds_to_coefficient_matrix(c0, A0, b0, lbx, ubx)
+        dev0 = P.standard_form_on_device(c, A, b, G, h)
+        assert np.array_equal(dev0.host(), A0) and np.array_equal(dev0.b32, b0) and np.array_equal(dev0.c32, c0)
+        dev1 = P.standard_form_on_device(c, A, b, G, h, lb, ub, artificials=True)
+        m1, n1 = A1.shape
+        assert dev1.core.shape == (m1, n1) and dev1.shape == (m1, n1 + m1) and dev1.artificial_from == n1
+        assert np.array_equal(dev1.core.host(), A1) and np.array_equal(dev1.b32, b1) and np.array_equal(dev1.core.c32, c1)
+        full = dev1.host()
+        assert np.array_equal(full[:, n1:], np.eye(m1, dtype=np.float32))
+        assert np.array_equal(dev1.c32, np.concatenate([np.zeros(n1), np.ones(m1)]).astype(np.float32))
+        assert np.array_equal(dev1.columns([0, n1 - 1, n1]), full[:, [0, n1 - 1, n1]])
+
+
 def test_primal_dual_is_a_dual_revised_solver_like_the_reference():
     """special_solvers.py:346: class PrimalDualAlgorithm(DualRevisedSimplexSolver)."""
     from linprog_amd.dual_solvers import DualRevisedSimplexSolver
