@@ -1,12 +1,18 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): kernel-trace stats of the default bench, then PMC passes for K1's HBM traffic.
+# Run on the GPU box (via gpurun): kernel-trace stats of the default bench (all three legs), then PMC passes for K1's HBM
+# traffic on the headline leg alone, then a kernel trace of config 2 (eager launches: one k_t_fused per pivot).
 # Usage: bash tools/profile_bench.sh <round-tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --cpu-pivots 0 > $OUT/bench_trace.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_fetch.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_write.log 2>&1 || exit 1
-find $OUT -name "*.csv" | head -20
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --cpu-pivots 0 > $OUT/bench_trace.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --headline-only --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_fetch.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --headline-only --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_write.log 2>&1 || exit 1
+LPX_GRAPH=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tableau1k -- python3 bench.py --workload tableau1k --steps 2000 --warmup 50 --cpu-pivots 0 > $OUT/bench_tableau1k_trace.log 2>&1 || exit 1
+timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --workload tableau1k --steps 4000 --warmup 100 > $OUT/bench_tableau1k.json 2>> $OUT/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --workload batch --steps 40 --warmup 5 > $OUT/bench_batch.json 2>> $OUT/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --workload config5 --steps 3 --warmup 1 > $OUT/bench_config5.json 2>> $OUT/bench_default.err || exit 1
+find $OUT -name "*kernel_stats.csv" | head

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -48,3 +48,19 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w", newline="") as f:
 if k1:
     json.dump(k1, open(os.path.join(dst, "k1_traffic.json"), "w"), indent=1)
     print(k1)
+
+# config 2's trace (eager launches: the single-launch chain shows as one k_t_fused per pivot) and the bench lines
+import shutil
+
+t1k = glob.glob(os.path.join(src, "trace_tableau1k", "*", "*_kernel_stats.csv"))
+if t1k:
+    rows = list(csv.reader(open(t1k[0])))
+    with open(os.path.join(dst, f"{tag}_tableau1k_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:120]
+            w.writerow(r)
+for name in ("bench_default", "bench_tableau1k", "bench_batch", "bench_config5"):
+    p = os.path.join(src, name + ".json")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{name}.json"))
