@@ -232,6 +232,17 @@ int lpx_build_standard_form(int64_t me, int64_t mi, int64_t nx, int64_t nb, int6
                             const float *G, const float *h, const int64_t *bound_var, const float *bound_sign,
                             const float *bound_val, float *out, int64_t ld, float *out_b, void *stream);
 
+/* PrimalDualAlgorithm.solve (special_solvers.py:402-447) as ONE launch for a small LP: s is the restricted-primal state
+ * on [A | I] (n = n_orig + m columns, costs 0 / 1); per outer iteration the admissible set (:405-406), a fresh restricted
+ * primal from the artificial basis (:408-425), and while its cost is positive y_rp, the unboundedness test (:435-436),
+ * theta (:438-443) and y += theta y_rp (:444).  ctrl->status: LPX_OPTIMAL, LPX_RUNNING (maxiters1 outer iterations done),
+ * LPX_DUAL_UNBOUNDED or LPX_PRIMAL_UNBOUNDED; ctrl->counter = outer iterations of this call, ctrl->pivots += inner pivots;
+ * x (n) / cost[0] = the last restricted primal's solution.  Call lpx_ctrl_begin_solve first.
+ * lpx_pd_small_lds_bytes(m, n_orig) <= 158 KiB says whether it fits, else LPX_E_SIZE. */
+int64_t lpx_pd_small_lds_bytes(int64_t m, int64_t n_orig);
+int lpx_pd_solve_small(const lpx_revised *s, double *y, const double *c64, int64_t n_orig, int64_t maxiters1,
+                       int64_t maxiters2, double *x, double *cost, void *stream);
+
 /* ----------------------------------------------------------------------------- tableau-form solver loop */
 int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
 /* `iters` primal iterations on an unpartitioned tableau (same rules as LPX_KIND_PRIMAL). */

@@ -81,6 +81,8 @@ _SIGS = {
     "lpx_pd_admissible": (C.c_int, [C.POINTER(LpxRevised), vp, vp, i64, vp, vp]),
     "lpx_pd_dual_step": (C.c_int, [C.POINTER(LpxRevised), vp, vp, vp, i64, vp, vp, vp]),
     "lpx_build_standard_form": (C.c_int, [i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+    "lpx_pd_small_lds_bytes": (i64, [i64, i64]),
+    "lpx_pd_solve_small": (C.c_int, [C.POINTER(LpxRevised), vp, vp, i64, i64, i64, vp, vp, vp]),
     "lpx_tableau_workspace_bytes": (i64, [i64, i64]),
     "lpx_tableau_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
     "lpx_tableau_msg_len": (i64, [i64]),

@@ -882,13 +882,18 @@ struct BlockArgs {
     const lpx_revised *states;   // device array, one per workgroup, all of the same m and n
     int64_t maxiters;
     double *x, *cost;            // optional per-LP results (batch-major: x is batch x n), or NULL
+    // primal-dual algorithm (PD = true): the state is the restricted primal [A | I], n = n_orig + m
+    double *pd_y;                // m, dual vector, in/out
+    const double *pd_c64;        // n_orig float64 costs of the unrestricted problem
+    int64_t pd_n_orig, pd_maxiters1;
 };
 struct BlockLds {
-    double *Binv, *xB, *y, *d, *e, *rowr, *w, *rc, *row, *lb, *ub, *bu;
+    double *Binv, *xB, *y, *d, *e, *rowr, *w, *rc, *row, *lb, *ub, *bu, *yd, *v;
     float *c, *cb;
     int *basis, *vstate;
     int64_t ldb, bytes;
 };
+#define LPX_KIND_PD 100 /* internal: LPX_KIND_PRIMAL inside the primal-dual outer loop */
 __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int kind, char *base)
 {
     BlockLds L;
@@ -911,6 +916,8 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
     L.lb = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
     L.ub = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
     L.bu = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
+    L.yd = (double *)take(kind == LPX_KIND_PD ? 8 * m : 0);
+    L.v = (double *)take(kind == LPX_KIND_PD ? 8 * n : 0);
     L.c = (float *)take(4 * n);
     L.cb = (float *)take(4 * m);
     L.basis = (int *)take(4 * m);
@@ -920,19 +927,28 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
 }
 #define LPX_BLOCK_LDS_MAX (158 * 1024)
 
-template <int KIND>
+// PD: PrimalDualAlgorithm.solve (special_solvers.py:402-447) around the primal loop -- per outer iteration the admissible
+// set J = isclose(y A, c) (:405-406), a FRESH restricted primal on [A_J | I] from the artificial basis (:408-425, the
+// reference's cold restart, float32 first iteration included), then while its cost is positive the restricted dual
+// y_rp = c_B B^-1, the unboundedness test (:435-436), theta (:438-443) and y += theta y_rp (:444).  One launch for the
+// whole algorithm instead of ~20 launches and two host round trips per outer iteration.
+template <int KIND, bool PD = false>
 __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ BatchRed red;
+    __shared__ double sh_cost;
     const lpx_revised s = a.states ? a.states[blockIdx.x] : a.single;
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
     const int m = (int)s.m, n = (int)s.n, t = threadIdx.x;
     const int64_t ldA = s.ldA;
-    const BlockLds L = block_lds(m, n, KIND, smem);
+    const BlockLds L = block_lds(m, n, PD ? LPX_KIND_PD : KIND, smem);
     const int ldb = (int)L.ldb;
     const float *A = s.A;
+    const int n_orig = PD ? (int)a.pd_n_orig : 0;
+    int64_t outer = 0;
+    int pd_status = LPX_RUNNING;
 
     // ---- solver state into LDS
     for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
@@ -953,6 +969,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     }
     __syncthreads();
     if (t < m) L.cb[t] = L.c[L.basis[t]];
+    if (PD && t < m) L.yd[t] = a.pd_y[t];
     bool f32 = ctrl->f32_phase != 0;
     int status = LPX_RUNNING;
     int64_t counter = ctrl->counter, pivots = ctrl->pivots;
@@ -986,6 +1003,30 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     };
     if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs();
 
+    do { // one pass, or the outer loop of the primal-dual algorithm
+    if (PD) {
+        outer += 1;
+        for (int col = t; col < n_orig; col += LPX_BLOCK) { // :405-406
+            const double v = block_dot_g<double, 32>(L.yd, 1, A + col, ldA, m);
+            const double cj = a.pd_c64[col];
+            L.v[col] = v;
+            L.vstate[col] = (fabs(v - cj) <= LPX_ATOL + LPX_RTOL * fabs(cj)) ? LPX_VS_LOWER : LPX_VS_EXCLUDED; // np.isclose
+        }
+        for (int idx = t; idx < m * m; idx += LPX_BLOCK) { // :408-424: artificial basis, B^-1 = I, bfs = b
+            const int i = idx / m, k = idx - i * m;
+            L.Binv[i * ldb + k] = (i == k) ? 1.0 : 0.0;
+        }
+        if (t < m) {
+            L.basis[t] = n_orig + t;
+            L.xB[t] = (double)s.b[t];
+            L.cb[t] = L.c[n_orig + t];
+            L.vstate[n_orig + t] = LPX_VS_BASIC;
+        }
+        f32 = true;
+        status = LPX_RUNNING;
+        counter = 0;
+        __syncthreads();
+    }
     for (int64_t it = 0; it < a.maxiters; ++it) {
         counter += 1;
         int r = 0, j = 0;
@@ -1169,6 +1210,51 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         __syncthreads();
         if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs(); // special_solvers.py:341
     }
+    if (PD) {
+        __syncthreads();
+        if (status == LPX_PRIMAL_UNBOUNDED) {
+            pd_status = LPX_PRIMAL_UNBOUNDED;
+            break;
+        }
+        // cost of the restricted primal, dot(c_rp, x) in index order (primal_solvers.py:72-79)
+        for (int col = t; col < n; col += LPX_BLOCK) L.rc[col] = 0.0;
+        __syncthreads();
+        if (t < m) L.rc[L.basis[t]] = L.xB[t];
+        __syncthreads();
+        if (t == 0) {
+            double s1 = 0.0;
+            for (int col = 0; col < n; ++col) s1 = fma((double)L.c[col], L.rc[col], s1);
+            sh_cost = s1;
+        }
+        __syncthreads();
+        if (!(sh_cost > 0.0)) { // :445-447: complementary slackness attained
+            pd_status = LPX_OPTIMAL;
+            break;
+        }
+        if (t < m) L.y[t] = batch_dot<double>(L.cb, 1, L.Binv + t, ldb, m); // y_rp = c_B B^-1 (:430-433, float64 inverse)
+        __syncthreads();
+        double th = LPX_INF, um = -LPX_INF;
+        for (int col = t; col < n_orig; col += LPX_BLOCK) {
+            const double u = block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+            if (L.vstate[col] == LPX_VS_EXCLUDED) th = fmin(th, lpx_psd(a.pd_c64[col] - L.v[col], u, false)); // :438-443
+            else um = fmax(um, u);
+        }
+        if (t < m) um = fmax(um, L.y[t]); // the artificial block of A_rp: y_rp @ I
+        int dummy = 0;
+        batch_argmin_max(th, dummy, um, red);
+        if (um <= 0.0) { // :435-436
+            pd_status = LPX_DUAL_UNBOUNDED;
+            break;
+        }
+        if (t < m) L.yd[t] = L.yd[t] + th * L.y[t]; // :444 (theta * y_rp, then +=: two roundings)
+        __syncthreads();
+    }
+    } while (PD && outer < a.pd_maxiters1);
+    if (PD) {
+        status = pd_status;
+        counter = outer;
+        if (t < m) a.pd_y[t] = L.yd[t];
+    }
 
     // ---- state back to HBM
     __syncthreads();
@@ -1250,6 +1336,39 @@ extern "C" int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t m
     a.states = nullptr;
     a.maxiters = maxiters;
     return block_launch(a, 1, s->m, s->n, kind, (hipStream_t)stream);
+}
+
+extern "C" int lpx_pd_solve_small(const lpx_revised *s, double *y, const double *c64, int64_t n_orig, int64_t maxiters1,
+                                  int64_t maxiters2, double *x, double *cost, void *stream)
+{
+    LPX_REQUIRE(s != nullptr && s->m > 0 && n_orig > 0 && s->n == n_orig + s->m, "the state must be the restricted primal [A | I]");
+    LPX_REQUIRE(s->A && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
+    LPX_REQUIRE(y && c64 && x && cost && maxiters1 >= 0 && maxiters2 >= 0, "bad arguments");
+    const int64_t bytes = block_lds(s->m, s->n, LPX_KIND_PD, nullptr).bytes;
+    if (bytes > LPX_BLOCK_LDS_MAX) {
+        lpx_set_error("lpx_pd_solve_small: the state of a %lld x %lld LP needs %lld B of LDS, one CU has %d", (long long)s->m,
+                      (long long)n_orig, (long long)bytes, LPX_BLOCK_LDS_MAX);
+        return LPX_E_SIZE;
+    }
+    if (maxiters1 == 0) return LPX_OK;
+    BlockArgs a{};
+    a.single = *s;
+    a.maxiters = maxiters2;
+    a.x = x;
+    a.cost = cost;
+    a.pd_y = y;
+    a.pd_c64 = c64;
+    a.pd_n_orig = n_orig;
+    a.pd_maxiters1 = maxiters1;
+    LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<LPX_KIND_PRIMAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((k_block_solve<LPX_KIND_PRIMAL, true>), dim3(1), dim3(LPX_BLOCK), (size_t)bytes, (hipStream_t)stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int64_t lpx_pd_small_lds_bytes(int64_t m, int64_t n_orig)
+{
+    if (m <= 0 || n_orig <= 0) return 0;
+    return block_lds(m, n_orig + m, LPX_KIND_PD, nullptr).bytes;
 }
 
 extern "C" int lpx_revised_solve_small_batch(const lpx_revised *dev_states, int64_t batch, int64_t m, int64_t n, int kind,

@@ -197,7 +197,24 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
         x_rp = None
         inner_basis = art_basis
         solved = False
-        while self.counter < maxiters1:
+        # Small problems: the whole algorithm is ONE launch (lpx_pd_solve_small: same steps in the same order, the inner
+        # solves bit-identical to the oracle's primal loop).  The per-outer-iteration logs exist only on the host path.
+        one_launch = (not warm_start and not self._LOG_CAP and eng.SMALL_SOLVE and m <= eng.SMALL_MAX_ROWS[_lib.KIND_PRIMAL]
+                      and lib.lpx_pd_small_lds_bytes(m, n) <= eng.SMALL_LDS_MAX)
+        if one_launch and self.counter < maxiters1:
+            _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, st))
+            _lib.check(lib.lpx_pd_solve_small(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, int(maxiters1 - self.counter),
+                                              int(maxiters2), eng.x.data_ptr(), eng.cost.data_ptr(), st))
+            ctrl = eng.read_ctrl()
+            self.counter += int(ctrl.counter)
+            self.inner_pivots += int(ctrl.pivots)
+            if ctrl.status == _lib.PRIMAL_UNBOUNDED:
+                raise PrimalIsUnboundedError
+            if ctrl.status == _lib.DUAL_UNBOUNDED:
+                raise DualIsUnboundedError  # :435-436
+            self.optimum = ctrl.status == _lib.OPTIMAL
+            solved = True
+        while not one_launch and self.counter < maxiters1:
             self.counter += 1
             _lib.check(lib.lpx_pd_admissible(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, v.data_ptr(), st))  # :405
             if warm_start and self.counter > 1:

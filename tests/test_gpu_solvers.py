@@ -333,6 +333,37 @@ def test_standard_form_on_device_equals_the_host_helpers():
         assert np.array_equal(dev1.columns([0, n1 - 1, n1]), full[:, [0, n1 - 1, n1]])
 
 
+@pytest.mark.parametrize("cs", [c for c in load("textbook.json") if c["solver"] == "PrimalDualAlgorithm"]
+                         + load("primal_dual.json") + [c for c in load("random.json") if c["solver"] == "PrimalDualAlgorithm"
+                                                       and c["ref"]["exception"] != "IndexError"],  # the reference's own crash
+                         ids=case_id)
+def test_primal_dual_one_launch_matches_reference(cs):
+    """PrimalDualAlgorithm without pivot logging runs as ONE launch (lpx_pd_solve_small): outer iteration count, x, basis,
+    cost and the raised exception equal the reference's goldens, and the total of inner pivots equals the golden trace's."""
+    from linprog_amd import exceptions
+    from linprog_amd.special_solvers import PrimalDualAlgorithm
+
+    ref = cs["ref"]
+    if "gen" in cs:
+        c, A, b, _ = problem_of(cs)
+    else:
+        c, A, b = np.array(cs["c"]), np.array(cs["A"]), np.array(cs["b"])
+    s = PrimalDualAlgorithm(c, A, b)
+    assert s._LOG_CAP == 0
+    if ref["exception"]:
+        with pytest.raises(getattr(exceptions, ref["exception"])):
+            s.solve(100000, 100000) if "gen" in cs else s.solve()
+        return
+    res = s.solve(100000, 100000) if "gen" in cs else s.solve()
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"]
+    assert s.inner_pivots == len(ref["pivots"])
+    assert res.basis.tolist() == ref["basis"]
+    assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+    if "optimal_bfs" in cs:  # tests/test_primal_dual_algorithm.py:11-16 asserts exact equality
+        assert np.array_equal(res.x, np.array(cs["optimal_bfs"], dtype=float))
+
+
 def test_primal_dual_is_a_dual_revised_solver_like_the_reference():
     """special_solvers.py:346: class PrimalDualAlgorithm(DualRevisedSimplexSolver)."""
     from linprog_amd.dual_solvers import DualRevisedSimplexSolver
