@@ -337,16 +337,22 @@ int lpx_batched_primal_solve_ineq(int64_t batch, int64_t m, int64_t k, const flo
 /* The same solver semantics per LP with the CONDENSED TABLEAU as carried state (nonbasic columns of B^-1 A, reduced-cost
  * row, x_B; lpx_tableau's layout) instead of B^-1: one rank-1 update per pivot, the tableau in registers, one wave per LP.
  * Arithmetic of the tableau loop (bit-identical to the oracle's lpo_tableau_solve), the reference's pivot sequences.
- * m <= 64, n - m <= 64; the starting basis is the slack block: columns n-m .. n-1 are the identity, their costs are 0,
- * b >= 0 (caller's check; no Binv0).  basis is output only. */
+ * One wave per LP for m <= 64, n - m <= 64; beyond, a grid of up to eight waves per LP (row groups x column groups, at
+ * most 64 rows per lane): m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128 (lpx_batched_tableau_waves != 0).
+ * The starting basis is the slack block: columns n-m .. n-1 are the identity, their costs are 0, b >= 0 (caller's
+ * check; no Binv0).  basis is output only. */
 int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                               int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                               int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
 /* The same for min c.x s.t. G x <= h, x >= 0 (preprocessing.py:17-69's [G | I] with its slack basis): G is m x k, c has k
- * entries, h >= 0, m <= 64, k <= 64; the identity block is never stored.  Results carry all k + m variables, slacks last. */
+ * entries, h >= 0, same shape limits with k for n - m; the identity block is never stored.  Results carry all k + m
+ * variables, slacks last. */
 int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t k, const float *G, const float *h, const float *c,
                                    int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                                    int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);
+/* Waves per LP that lpx_batched_tableau_solve / _ineq use for m rows and k = n - m nonbasic columns; 0: the shape does not
+ * fit (the caller takes lpx_batched_primal_solve).  Host-only, no device needed.  No counterpart in the reference. */
+int lpx_batched_tableau_waves(int64_t m, int64_t k);
 /* lpx_batched_tableau_solve from ANY primal feasible starting basis (primal_solvers.py:37-53).  The caller forms the
  * starting tableau with the reference's float32 expressions and passes it: T0 = (inv(A_B) A)[:, nonbasic] (m x k per LP,
  * k = n - m), rc0 = its reduced costs (k), xb0 = inv(A_B) b (m), var0 = the variable of every column (k), basis (m, input

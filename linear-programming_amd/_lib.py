@@ -107,6 +107,7 @@ _SIGS = {
     "lpx_batched_tableau_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_batched_tableau_solve_ineq": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_batched_tableau_dual_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "lpx_batched_tableau_waves": (C.c_int, [i64, i64]),
     "lpx_batched_tableau_solve_from": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_pivot_update": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, vp]),
     "lpx_pivot_update_static": (C.c_int, [vp, i64, i64, i64, i64, vp, vp]),

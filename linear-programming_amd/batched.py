@@ -133,7 +133,9 @@ class BatchedTableauSolver(BatchedPrimalSolver):
     """The same per-LP semantics with the condensed tableau as carried state (``lpx_batched_tableau_solve``): one rank-1
     update per pivot instead of three chains of m dependent fmas, the tableau in registers.  Bit-identical to the oracle's
     tableau loop; from the slack basis with zero basic costs (``from_inequalities``, every synthetic config) the kernel
-    reads A itself and takes the reference's pivot sequences, x and cost within 1e-9.  m <= 64, n - m <= 64.
+    reads A itself and takes the reference's pivot sequences, x and cost within 1e-9.  One wave per LP for m <= 64 and
+    n - m <= 64; a grid of up to eight waves per LP (``k_batched_tab_grid``) up to m <= 128 with n - m <= 256 or m <= 256
+    with n - m <= 128.
     From any other primal feasible basis the float32 starting tableau ``inv32 @ A`` is formed on the host as the
     reference's constructor state and CARRIED for the whole solve, whereas the reference recomputes ``inv64 @ A`` in
     float64 from its second pivot on: x and cost then agree with the reference and with the revised-form kernel to
@@ -143,13 +145,15 @@ class BatchedTableauSolver(BatchedPrimalSolver):
     def __init__(self, c, A, b, basis, log_cap=0):
         super().__init__(c, A, b, basis, log_cap=log_cap)  # preprocessing, feasibility check (primal_solvers.py:41-53)
         k = self.n - self.m
-        if self.m > 64 or k > 64:
-            raise ValueError("BatchedTableauSolver: m <= 64 and n - m <= 64")
+        if not self.lib.lpx_batched_tableau_waves(self.m, k):
+            raise ValueError("BatchedTableauSolver: m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128")
         c32 = np.asarray(c).astype(np.float32)
         basis = np.asarray(basis).astype(np.int64)
         self.start = None
         slack = (self.Binv0 is None and np.array_equal(basis, np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
                  and not np.any(c32[:, k:] != 0))
+        if not slack and (self.m > 64 or k > 64):
+            raise ValueError("BatchedTableauSolver from a general starting basis: m <= 64 and n - m <= 64")
         if not slack:
             # any other start: the reference's float32 constructor state (:37-38, :64) carried as a condensed tableau,
             # formed per LP on the host with the reference's own NumPy expressions
@@ -173,8 +177,8 @@ class BatchedTableauSolver(BatchedPrimalSolver):
     @classmethod
     def from_inequalities(cls, c, G, h, log_cap=0):
         self = super().from_inequalities(c, G, h, log_cap=log_cap)
-        if self.m > 64 or self.ineq_k > 64:
-            raise ValueError("BatchedTableauSolver: m <= 64 and k <= 64")
+        if not self.lib.lpx_batched_tableau_waves(self.m, self.ineq_k):
+            raise ValueError("BatchedTableauSolver: m <= 128 with k <= 256, or m <= 256 with k <= 128")
         return self
 
     def enqueue(self, maxiters):
@@ -323,7 +327,7 @@ class BatchedBoundedSolver:
 def solve_many(problems, maxiters=100, form="revised"):
     """Front-end for a LIST of LPs ``(c, A, b, basis)`` of mixed shapes: LPs of equal shape go into one launch, the
     launches of different shapes run on separate streams, results come back in input order.  ``form="tableau"``: groups
-    that qualify (SLACK start with zero basic costs, m <= 64, n - m <= 64) go through the faster condensed-tableau kernel,
+    that qualify (SLACK start with zero basic costs, up to 128 x 256 or 256 x 128 tableau slots) go through the faster condensed-tableau kernel,
     whose x and cost agree with the revised form's to 1e-9 (same pivots) rather than bit for bit; every other group --
     any non-slack starting basis included -- takes the revised-form kernels in both modes (bit-identical to the oracle's
     revised loop from the same float32 starting inverse; the tableau kernel would carry a float32 starting tableau for

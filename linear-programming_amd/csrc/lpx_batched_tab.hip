@@ -26,6 +26,17 @@ __device__ __forceinline__ double tb_readlane(double v, int lane)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// x = fma(v[lane], p, x) with the readlanes and the fma pinned in program order: left to the compiler, the readlanes of a
+// whole unrolled column are issued first and the scalars they produce are spilled (v_writelane) and read back
+#define TB_FMA_LANE(xv, elo, ehi, LANE, p)                                                                               \
+    do {                                                                                                                \
+        int lo_, hi_;                                                                                                   \
+        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(lo_) : "v"(elo), "n"(LANE));                                    \
+        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(hi_) : "v"(ehi), "n"(LANE));                                    \
+        const double ei_ = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned)lo_)); \
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(xv) : "s"(ei_), "v"(p));                                            \
+    } while (0)
+
 struct TabBatchArgs {
     int64_t batch, m, n;
     const float *A, *b, *c;
@@ -154,15 +165,29 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
 #undef TB_GET
             }
         }
-        // One select per element covers both special cases: the pivot row (every lane) and the entering lane (every row)
-        // take their addend from -0.0 -- fma(e_r, row_r, -0.0) is the plain product, and with the entering lane's
-        // multiplicand set to 1 fma(e_i, 1, -0.0) is e_i itself, bit for bit.
+        // Two special cases take their addend from -0.0: the pivot row in every lane -- fma(e_r, row_r, -0.0) is the plain
+        // product -- and every row of the entering lane, whose multiplicand is 1: fma(e_i, 1, -0.0) is e_i itself, bit for
+        // bit.  Neither costs a select per element: the entering lane clears its column under its own exec mask, and only
+        // the 8 rows around the pivot row (a scalar branch) run selects.  The update is then 2 readlanes + 1 fma per row.
         const bool mine = t == jl;
         const double prs = mine ? 1.0 : pr;
+        if (mine) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const double ei = tb_readlane(e, i);
-            x[i] = fma(ei, prs, (mine || i == r) ? -0.0 : x[i]);
+            for (int i = 0; i < MR; ++i) x[i] = -0.0;
+        }
+        {
+            const long long eb = __double_as_longlong(e);
+            const int elo = (int)(eb & 0xffffffffLL), ehi = (int)(eb >> 32);
+            const int rchunk = r >> 3;
+#pragma unroll
+            for (int c = 0; c < MR / 8; ++c) {
+                if (rchunk == c) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[8 * c + j] = (8 * c + j == r) ? -0.0 : x[8 * c + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) TB_FMA_LANE(x[8 * c + j], elo, ehi, 8 * c + j, prs);
+            }
         }
         rc = fma(em, prs, mine ? -0.0 : rc);
         if (mine) var = leaving;
@@ -195,9 +220,12 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     }
 }
 
+extern "C" int lpx_batched_tableau_waves(int64_t m, int64_t k);
+static int tab_launch_multi(const TabBatchArgs &a, void *stream);
 template <bool DUAL>
 static int tab_launch(const TabBatchArgs &a, void *stream)
 {
+    if (!DUAL && a.T0 == nullptr && (a.m > TB_MAX || a.n - a.m > TB_MAX)) return tab_launch_multi(a, stream);
     const dim3 grid((unsigned)a.batch), block(64);
     hipStream_t st = (hipStream_t)stream;
     if (a.m <= 16) hipLaunchKernelGGL((k_batched_tab<16, DUAL>), grid, block, 0, st, a);
@@ -209,7 +237,7 @@ static int tab_launch(const TabBatchArgs &a, void *stream)
 }
 
 // PrimalRevisedSimplexSolver(c, A, b, basis).solve(maxiters) per LP (primal_solvers.py:176-263) in condensed tableau form.
-// m <= 64, n - m <= 64; starting basis = the slack block (columns n-m .. n-1 are the identity, b >= 0) with zero costs on
+// Shapes: lpx_batched_tableau_waves(m, n - m) != 0; starting basis = the slack block (columns n-m .. n-1 are the identity, b >= 0) with zero costs on
 // it -- the caller's check.  Arrays batch-major as in lpx_batched_primal_solve; basis is written (m per LP).
 extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                                          int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters,
@@ -218,7 +246,10 @@ extern "C" int lpx_batched_tableau_solve(int64_t batch, int64_t m, int64_t n, co
     LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
-    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    if (!lpx_batched_tableau_waves(m, n - m)) {
+        lpx_set_error("lpx_batched_tableau_solve: m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128 (up to eight waves per LP)");
+        return LPX_E_SIZE;
+    }
     return tab_launch<false>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
@@ -231,7 +262,10 @@ extern "C" int lpx_batched_tableau_solve_ineq(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(batch > 0 && m > 0 && k > 0 && maxiters >= 0, "bad sizes");
     LPX_REQUIRE(G && h && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
-    LPX_REQUIRE(m <= TB_MAX && k <= TB_MAX, "m <= 64 and k <= 64 (one lane per row and per structural column)");
+    if (!lpx_batched_tableau_waves(m, k)) {
+        lpx_set_error("lpx_batched_tableau_solve_ineq: m <= 128 with k <= 256, or m <= 256 with k <= 128 (up to eight waves per LP)");
+        return LPX_E_SIZE;
+    }
     return tab_launch<false>(TabBatchArgs{batch, m, k + m, G, h, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, k, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
@@ -265,4 +299,243 @@ extern "C" int lpx_batched_tableau_solve_from(int64_t batch, int64_t m, int64_t 
     return tab_launch<false>(TabBatchArgs{batch, m, n, T0, xb0, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, T0, rc0,
                                           xb0, var0},
                              stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same kernel for LPs beyond one wave: a GRID of RW x CW waves per LP (one workgroup).  Wave (rg, cg) carries rows
+// rg*MRL .. rg*MRL+MRL-1 of column slots cg*64 .. cg*64+63: at most 64 rows per lane whatever m is, so the register count
+// stays that of the one-wave kernel (three waves per SIMD) where a single column of up to 128 rows per lane would leave
+// one wave per SIMD and nothing to hide a barrier behind.  Thread t of the workgroup also owns row t (x_B[t], basis[t]).
+// What the one-wave kernel moves between lanes with v_readlane and ballots goes through a few words of LDS here, four
+// exchanges per pivot, one barrier each:
+//   (A) pricing: per column group "any rc < 0", "any rc < -1e-8" and the smallest negative variable id packed with its
+//       slot (ids are distinct, so the minimum of id * 256 + slot names the entering slot as well); every row group
+//       keeps its own copy of the reduced costs (same fma, same bits), row group 0 reports;
+//   (B) the entering column: its owner in every row group writes its MRL rows;
+//   (C) the ratio test's per-wave candidates (theta, row, x_B, basic variable): rows ascend with the thread, first
+//       minimum wins;
+//   (D) the eta column e and the pivot row (written by the row group that holds row r).
+// The update itself is one fma per element with no selects: the pivot row's addend is set to -0.0 by the scalar switch
+// that fetches it, the entering slot's lane sets its column to -0.0 under its own exec mask (one wave in CW pays for it).
+// Same arithmetic, same order: bit-identical to lpo_tableau_solve and to the one-wave kernel on shapes both take.
+// Shapes: RW * CW <= 8 waves, i.e. m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128.  Primal rules, slack start
+// (or inequality form).
+// ---------------------------------------------------------------------------------------------------------
+#define TBG_MAX_N 512
+struct Tab2Price {
+    int64_t key; // smallest negative variable id * 256 + its column slot (INT64_MAX: none)
+    int anyneg, anyopen;
+};
+struct Tab2Ratio {
+    double th, xb;
+    int row, bas, anypos, pad;
+};
+
+template <int MRL, int RW, int CW>
+__global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab_grid(TabBatchArgs a)
+{
+    constexpr int NW = RW * CW, NT = 64 * NW, M = RW * MRL, NRW = (M + 63) / 64;
+    static_assert(MRL % 8 == 0 && MRL <= 64 && NW <= 16 && 64 * CW <= 256, "shape");
+    __shared__ __attribute__((aligned(16))) double dcol[M + 2];
+    __shared__ __attribute__((aligned(16))) double es[M + 64];
+    __shared__ double prow[64 * CW];
+    __shared__ double xs[TBG_MAX_N];
+    __shared__ float cf[TBG_MAX_N];
+    __shared__ Tab2Price shp[CW];
+    __shared__ Tab2Ratio shr[NRW];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int rg = wave / CW, cg = wave - rg * CW;
+    const int cs = cg * 64 + lane; // this lane's column slot
+    const int r0 = rg * MRL;       // first row of this wave's row group
+    const int64_t lp = blockIdx.x;
+    const int m = (int)a.m, n = (int)a.n, k = n - m;
+    const bool col = cs < k, row = t < m;
+    const int na = (int)a.na;
+    const float *A = a.A + lp * a.m * a.na;
+
+    double x[MRL];
+#pragma unroll
+    for (int i = 0; i < MRL; ++i) x[i] = (col && r0 + i < m) ? (double)A[(int64_t)(r0 + i) * na + cs] : 0.0;
+    double rc = col ? (double)a.c[lp * na + cs] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+    double xb = row ? (double)a.b[lp * m + t] : 0.0;
+    int var = col ? cs : 0x7FFFFFFF; // variable held by this lane's column slot
+    int bas = row ? k + t : -1;      // basis[t]
+    for (int j = t; j < n; j += NT) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
+    if (t < 64) es[M + t] = 0.0; // the tail a whole-wave read of a short row group touches
+
+    bool f32 = true; // the first ratio test divides in float32
+    int32_t status = LPX_RUNNING;
+    int64_t counter = 0, pivots = 0;
+    while (counter < a.maxiters) {
+        counter += 1;
+        // ---- (A) pricing (primal_solvers.py:135-142)
+        if (rg == 0) {
+            const bool neg = col && rc < 0.0;
+            const int64_t mine_key = neg ? (((int64_t)var << 8) | cs) : INT64_MAX; // ids < 2^31, slots < 256
+            const int64_t kmin = wave_imin(mine_key);
+            const int anyn = __ballot(neg) != 0, anyo = __ballot(col && rc < -LPX_ATOL) != 0;
+            if (lane == 0) shp[cg] = Tab2Price{kmin, anyn, anyo};
+        }
+        __syncthreads();
+        int64_t key = INT64_MAX;
+        bool anyneg = false, anyopen = false;
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+            const Tab2Price p = shp[w];
+            key = p.key < key ? p.key : key;
+            anyneg = anyneg || p.anyneg;
+            anyopen = anyopen || p.anyopen;
+        }
+        if (!anyneg || !anyopen) { // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (:140-142)
+            status = LPX_OPTIMAL;
+            break;
+        }
+        const int jv = (int)(key >> 8), jl = (int)(key & 0xFF); // first negative index by variable id, and its slot
+        const bool mine = cs == jl;                               // one lane in every row group
+        // ---- (B) entering column (:149-152)
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < MRL; ++i) dcol[r0 + i] = x[i];
+            if (rg == 0) dcol[M] = rc;
+        }
+        __syncthreads();
+        const double d = row ? dcol[t] : 0.0;
+        const double rcj = dcol[M];
+        // ---- (C) ratio test (:154-167)
+        if (wave < NRW) {
+            const double th = row ? lpx_psd(xb, d, f32) : LPX_INF;
+            const double thmin = wave_min(th);
+            const unsigned long long who = __ballot(th == thmin); // rows ascend with the lane: first lane = np.argmin
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+            const double xbs = tb_readlane(xb, src);
+            const int bs = __builtin_amdgcn_readlane(bas, src);
+            const int anypos = __ballot(row && d > 0.0) != 0;
+            if (lane == 0) shr[wave] = Tab2Ratio{thmin, xbs, wave * 64 + src, bs, anypos, 0};
+        }
+        __syncthreads();
+        Tab2Ratio best = shr[0];
+#pragma unroll
+        for (int w = 1; w < NRW; ++w) {
+            const Tab2Ratio q = shr[w];
+            const bool take = q.th < best.th; // strict: the earlier wave (lower rows) keeps ties
+            const int ap = best.anypos | q.anypos;
+            if (take) best = q;
+            best.anypos = ap;
+        }
+        if (!best.anypos) { // max(d) <= 0 (:144-147)
+            status = LPX_PRIMAL_UNBOUNDED;
+            break;
+        }
+        const int r = __builtin_amdgcn_readfirstlane(best.row); // the same in every lane: make it a scalar
+        const double dr = dcol[r], xr = best.xb;
+        const int leaving = best.bas;
+        // ---- (D) eta column (:236-244), x_B (:251-253), pivot row
+        const double em = (-rcj) / dr; // eliminates the entering column's reduced cost
+        if (wave < NRW) {
+            const double e = ((t == r) ? 1.0 : -d) / dr; // rows >= m: d = 0, e = -0: they stay 0
+            if (t < M) es[t] = e;
+            if (row) xb = (t == r) ? e * xr : fma(e, xr, xb);
+        }
+        const int rr = r / MRL, rl = r - rr * MRL;
+        double pr = 0.0;
+        if (rg == rr) {
+            switch (rl) { // this column's pivot-row entry; its addend becomes -0.0: fma(e_r, row_r, -0.0) is the plain product
+#define TB_GET(i) case (i): if constexpr ((i) < MRL) pr = x[(i) < MRL ? (i) : 0]; break;
+                TB_ROWS(TB_GET)
+#undef TB_GET
+            }
+            prow[cs] = pr;
+        }
+        __syncthreads();
+        if (rg != rr) pr = prow[cs];
+        // the entering slot receives the eta column itself: multiplicand 1, addends -0.0 (fma(e_i, 1, -0.0) = e_i bit for bit)
+        const double prs = mine ? 1.0 : pr;
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < MRL; ++i) x[i] = -0.0;
+        }
+        // the pivot row's addend is -0.0 as well (fma(e_r, row_r, -0.0) is the plain product): a select on a scalar condition
+        const int rlm = (rg == rr) ? rl : -1;
+        {
+            const double ew = es[r0 + lane]; // lane i of every wave of the row group holds e of its row i
+            const long long eb = __double_as_longlong(ew);
+            const int elo = (int)(eb & 0xffffffffLL), ehi = (int)(eb >> 32);
+            const int rchunk = rlm >> 3; // only the 8 rows around the pivot row pay for the selects: a scalar branch
+#pragma unroll
+            for (int c = 0; c < MRL / 8; ++c) {
+                if (rchunk == c) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[8 * c + j] = (8 * c + j == rlm) ? -0.0 : x[8 * c + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) TB_FMA_LANE(x[8 * c + j], elo, ehi, 8 * c + j, prs);
+            }
+        }
+        rc = fma(em, prs, mine ? -0.0 : rc);
+        if (mine) var = leaving;
+        if (t == r) bas = jv; // :261
+        if (a.log && t == 0 && pivots < a.log_cap) {
+            int64_t *lg = a.log + (lp * a.log_cap + pivots) * 3;
+            lg[0] = r;
+            lg[1] = jv;
+            lg[2] = leaving;
+        }
+        pivots += 1;
+        f32 = false;
+    }
+
+    // ---- result: x = scatter(x_B), cost = dot(c, x) in index order (primal_solvers.py:72-79)
+    __syncthreads();
+    for (int j = t; j < n; j += NT) xs[j] = 0.0;
+    __syncthreads();
+    if (row) xs[bas] = xb;
+    __syncthreads();
+    for (int j = t; j < n; j += NT) a.x[lp * n + j] = xs[j];
+    if (row) a.basis[lp * m + t] = bas;
+    if (t == 0) {
+        double s1 = 0.0;
+        for (int jx = 0; jx < n; ++jx) s1 = fma((double)cf[jx], xs[jx], s1);
+        a.cost[lp] = s1;
+        a.status[lp] = status;
+        a.iters[lp] = counter;
+        a.pivots[lp] = pivots;
+    }
+}
+
+// waves per LP for a shape, 0 if it does not fit a workgroup of 8 waves
+extern "C" int lpx_batched_tableau_waves(int64_t m, int64_t k)
+{
+    if (m <= 0 || k <= 0 || m > 256 || k > 256) return 0;
+    const int rw = m <= 64 ? 1 : m <= 128 ? 2 : 4, cw = (int)((k + 63) / 64);
+    return rw * cw <= 8 ? rw * cw : 0;
+}
+
+static int tab_launch_multi(const TabBatchArgs &a, void *stream)
+{
+    const int m = (int)a.m, k = (int)(a.n - a.m);
+    const int rw = m <= 64 ? 1 : m <= 128 ? 2 : 4, cw = (k + 63) / 64;
+    const int per = (m + rw - 1) / rw, mrl = per <= 16 ? 16 : (per + 7) / 8 * 8; // rows per lane, in steps of 8
+    const dim3 grid((unsigned)a.batch), block((unsigned)(64 * rw * cw));
+    hipStream_t st = (hipStream_t)stream;
+    bool done = false;
+#define TBG_GO(MRLv, RWv, CWv)                                                                                          \
+    if (!done && mrl == MRLv && rw == RWv && cw == CWv) {                                                              \
+        hipLaunchKernelGGL((k_batched_tab_grid<MRLv, RWv, CWv>), grid, block, 0, st, a);                               \
+        done = true;                                                                                                   \
+    }
+#define TBG_ROWSN(RWv, CWv) TBG_GO(40, RWv, CWv) TBG_GO(48, RWv, CWv) TBG_GO(56, RWv, CWv) TBG_GO(64, RWv, CWv)
+#define TBG_ROWS1(CWv) TBG_GO(16, 1, CWv) TBG_GO(24, 1, CWv) TBG_GO(32, 1, CWv) TBG_ROWSN(1, CWv)
+    TBG_ROWS1(2) TBG_ROWS1(3) TBG_ROWS1(4)
+    TBG_ROWSN(2, 1) TBG_ROWSN(2, 2) TBG_ROWSN(2, 3) TBG_ROWSN(2, 4)
+    TBG_ROWSN(4, 1) TBG_ROWSN(4, 2)
+#undef TBG_ROWSN
+#undef TBG_ROWS1
+#undef TBG_GO
+    if (!done) {
+        lpx_set_error("lpx_batched_tableau_solve: no kernel for m = %d, n - m = %d", m, k);
+        return LPX_E_SIZE;
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
 }

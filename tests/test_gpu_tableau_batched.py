@@ -340,7 +340,7 @@ def test_solve_many_mixed_shapes():
     for p, r in zip(probs, res):
         o = O.OracleRevised(*p, log_cap=4).solve(100000)
         assert r.optimum and r.iters == o.iters and np.array_equal(r.x, o.x) and r.cost == o.cost
-    fast = solve_many(probs, 100000, form="tableau")  # (80, 170) does not fit a wave: it stays on the generic kernel
+    fast = solve_many(probs, 100000, form="tableau")  # (80, 170) does not fit a wave: two waves per LP take it
     for r, f in zip(res, fast):
         assert f.optimum and f.iters == r.iters and f.basis.tolist() == r.basis.tolist()
         assert_close(f.x, r.x, "x")
@@ -442,7 +442,9 @@ def test_tableau_without_nonbasic_columns_falls_back_to_the_full_layout():
     assert np.allclose(t.x, r.x, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("m,n", [(4, 8), (5, 12), (16, 32), (37, 100), (40, 104), (64, 128), (61, 125), (64, 70)])
+@pytest.mark.parametrize("m,n", [(4, 8), (5, 12), (16, 32), (37, 100), (40, 104), (64, 128), (61, 125), (64, 70),
+                                 (80, 170), (96, 192), (64, 256), (70, 80), (65, 130), (128, 256), (100, 340), (30, 200),
+                                 (128, 384)])
 def test_batched_tableau_kernel_bit_identical_to_the_tableau_oracle(m, n):
     """lpx_batched_tableau_solve (condensed tableau in registers, one wave per LP): per LP the pivot log, x, cost, basis and
     iters of the oracle's tableau loop, bit for bit, on full solves and on solves cut off by maxiters; the revised-form
@@ -455,11 +457,21 @@ def test_batched_tableau_kernel_bit_identical_to_the_tableau_oracle(m, n):
     for maxiters in (100000, 7):
         tab = BatchedTableauSolver(*args, log_cap=4096)
         rt = tab.solve(maxiters)
-        rev = BatchedPrimalSolver(*args, log_cap=4096)
-        rr = rev.solve(maxiters)
+        from linprog_amd.exceptions import LpxBackendError
+
+        try:  # beyond one wave the multi-wave kernel also takes shapes that the LDS-resident revised kernels cannot hold
+            rev = BatchedPrimalSolver(*args, log_cap=4096)
+            rr = rev.solve(maxiters)
+        except LpxBackendError:
+            assert m > 64 or n > 256
+            rev = rr = None
         for i, p in enumerate(probs):
             o = O.OracleTableau(*p, log_cap=4096).solve(maxiters)
-            assert tab.pivot_logs()[i].tolist() == o.log.tolist() == rev.pivot_logs()[i].tolist()
+            assert tab.pivot_logs()[i].tolist() == o.log.tolist()
+            if rev is None:
+                assert rt[i].iters == o.iters and np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
+                continue
+            assert o.log.tolist() == rev.pivot_logs()[i].tolist()
             assert rt[i].iters == o.iters and rt[i].optimum == (o.status == O.OPTIMAL)
             assert np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
             assert rt[i].basis.tolist() == o.basis.tolist()
@@ -491,10 +503,10 @@ def test_batched_tableau_kernel_reference_sequences_and_unbounded():
     assert sol.raw["status"].tolist() == [_lib.OPTIMAL, _lib.PRIMAL_UNBOUNDED, _lib.OPTIMAL]
     assert np.array_equal(out[0].x, res[0].x) and np.array_equal(out[2].x, res[2].x)
     with pytest.raises(ValueError):
-        BatchedTableauSolver(*[np.stack([p[k] for p in [gen.gen_primal(70, 140, 0)]]) for k in range(4)])  # m > 64
+        BatchedTableauSolver(*[np.stack([p[k] for p in [gen.gen_primal(130, 260, 0)]]) for k in range(4)])  # m > 128
 
 
-@pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 60)])
+@pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 60), (80, 90), (64, 192), (128, 128)])
 def test_batched_tableau_inequality_form_equals_materialised_problem(m, k):
     """lpx_batched_tableau_solve_ineq (G x <= h; the slack identity is never stored) returns the same bits as the
     standard-form entry point on [G | I]."""
