@@ -13,6 +13,19 @@
 #include "lpx_device.hpp"
 
 #define TB_MAX 64
+// diagnostic build only (tools/tab_cycles.hip): resident cycles and pivots summed over the workgroups of a launch
+#ifdef LPX_TAB_STAMPS
+__device__ unsigned long long g_tab_stamps[2];
+#define TB_STAMP_BEGIN const unsigned long long tb_t0 = clock64();
+#define TB_STAMP_END                                                      \
+    if (threadIdx.x == 0) {                                               \
+        atomicAdd(&g_tab_stamps[0], clock64() - tb_t0);                   \
+        atomicAdd(&g_tab_stamps[1], (unsigned long long)pivots);          \
+    }
+#else
+#define TB_STAMP_BEGIN
+#define TB_STAMP_END
+#endif
 // one case per row: r is wave-uniform, so "register r of this lane" is a scalar branch, not 64 selects
 #define TB_ROWS8(F, b) F(b + 0) F(b + 1) F(b + 2) F(b + 3) F(b + 4) F(b + 5) F(b + 6) F(b + 7)
 #define TB_ROWS(F) TB_ROWS8(F, 0) TB_ROWS8(F, 8) TB_ROWS8(F, 16) TB_ROWS8(F, 24) TB_ROWS8(F, 32) TB_ROWS8(F, 40) TB_ROWS8(F, 48) TB_ROWS8(F, 56)
@@ -64,6 +77,7 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     __shared__ double dcol[TB_MAX + 2];
     __shared__ double xs[2 * TB_MAX];
     __shared__ float cf[2 * TB_MAX];
+    TB_STAMP_BEGIN
     const int t = threadIdx.x;
     const int64_t lp = blockIdx.x;
     const int m = (int)a.m, n = (int)a.n, k = n - m;
@@ -148,9 +162,10 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
                 status = LPX_PRIMAL_UNBOUNDED;
                 break;
             }
-            VI th{row ? lpx_psd(xb, d, f32) : LPX_INF, row ? (int64_t)t : LPX_NOIDX};
-            th = wave_argmin(th); // first argmin (:165-166)
-            r = __builtin_amdgcn_readfirstlane((int)th.i);
+            const double th = row ? lpx_psd(xb, d, f32) : LPX_INF;
+            const double thmin = wave_min(th);
+            // rows ascend with the lane: the first lane at the minimum is np.argmin's first argmin (:165-166)
+            r = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(th == thmin)) - 1);
         }
         dr = tb_readlane(d, r);
         const double e = ((t == r) ? 1.0 : -d) / dr; // :236-244: 1/d_r or (-d_i)/d_r (lanes >= m: d = 0, e = -0, rows stay 0)
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         a.iters[lp] = counter;
         a.pivots[lp] = pivots;
     }
+    TB_STAMP_END
 }
 
 extern "C" int lpx_batched_tableau_waves(int64_t m, int64_t k);
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
     __shared__ float cf[TBG_MAX_N];
     __shared__ Tab2Price shp[CW];
     __shared__ Tab2Ratio shr[NRW];
+    TB_STAMP_BEGIN
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int rg = wave / CW, cg = wave - rg * CW;
@@ -501,6 +518,7 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
         a.iters[lp] = counter;
         a.pivots[lp] = pivots;
     }
+    TB_STAMP_END
 }
 
 // waves per LP for a shape, 0 if it does not fit a workgroup of 8 waves
