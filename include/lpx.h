@@ -278,6 +278,15 @@ int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, void *stream);
 int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, void *stream);
 /* Part 2, after an all-gather of the proposals: global first argmin of theta, update of the local slice. */
 int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvbuf, int64_t nranks, void *stream);
+/* The same pivot split in two so that the all-gather of pivot t+1 overlaps the update of pivot t (same reference lines:
+ * dual_solvers.py:47-80, primal_solvers.py:247-253).  dual_commit_begin = entering decision and eta column of this pivot
+ * and, when sendbuf_next != NULL, the NEXT pivot's leaving row (first negative entry of the x_B column as the update will
+ * leave it) and this rank's proposal for it, formed from the old tableau, e and the old pivot row exactly as the update
+ * will write them.  adopt != 0: this pivot's leaving row is the one the previous call decided ahead (it could not go
+ * into the control block while that pivot's update was still to read it); adopt == 0: lpx_tableau_dual_propose decided
+ * it.  The update itself is lpx_tableau_commit_update. */
+int lpx_tableau_dual_commit_begin(const lpx_tableau *s, const double *recvbuf, int64_t nranks, int adopt,
+                                  double *sendbuf_next, void *stream);
 
 /* ------------------------------------------------------- opt-in: fp64 refinement of the product-form inverse */
 /* No counterpart in the reference's revised solvers, which multiply eta matrices for the whole solve

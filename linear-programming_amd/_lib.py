@@ -100,6 +100,7 @@ _SIGS = {
     "lpx_tableau_dual_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
     "lpx_tableau_dual_propose": (C.c_int, [C.POINTER(LpxTableau), vp, vp]),
     "lpx_tableau_dual_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
+    "lpx_tableau_dual_commit_begin": (C.c_int, [C.POINTER(LpxTableau), vp, i64, C.c_int, vp, vp]),
     "lpx_tableau_expand": (C.c_int, [C.POINTER(LpxTableau), vp, vp, vp, vp]),
     "lpx_batched_primal_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "lpx_batched_dual_solve": (C.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),

@@ -32,6 +32,7 @@ struct TabWs {
     FusedPart fp[2];
     double *next[2]; // {min rc, entering variable, its column slot, optimal?}
     int64_t *base;   // pivots at the start of the current lpx_tableau_iterate call
+    double *pend;    // partitioned dual loop with lookahead: {leaving row, optimal?, min x_B} decided one pivot ahead
     int64_t bytes;
 };
 static inline char *tcarve(char *&p, int64_t bytes)
@@ -67,6 +68,7 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
         w.next[q] = (double *)tcarve(p, 8 * 8);
     }
     w.base = (int64_t *)tcarve(p, 8 * 2);
+    w.pend = (double *)tcarve(p, 8 * 4);
     w.bytes = (int64_t)(p - (char *)base);
     return w;
 }
@@ -1312,10 +1314,26 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_propose(lpx_tableau s, Partial
 // index on ties" is np.argmin's first minimum, whichever rank holds the variable).  No candidate anywhere
 // (every theta = +inf) is exactly min(row) >= 0: dual unbounded.
 __global__ __launch_bounds__(LPX_BLOCK) void k_td_commit(lpx_tableau s, const double *recv, int64_t nranks, int64_t msg, double *d,
-                                                        double *e, double *rowr)
+                                                        double *e, double *rowr, const double *pend)
 {
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
+    int64_t r;
+    if (pend != nullptr) {
+        // lookahead: this pivot's leaving row was decided by the previous pivot's k_td_ratio_next, which may not touch
+        // the control block (that pivot's K1 still had to read it): adopt the decision here, as k_td_ratio would have
+        r = (int64_t)pend[0];
+        const bool opt = pend[1] != 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->counter += 1;
+            ctrl->price_val = pend[2];
+            if (opt) ctrl->status = LPX_OPTIMAL;
+            else ctrl->leave_r = r;
+        }
+        if (opt) return;
+    } else {
+        r = ctrl->leave_r;
+    }
     VI best{LPX_INF, LPX_NOIDX};
     int64_t win = 0;
     for (int64_t g = 0; g < nranks; ++g) {
@@ -1330,10 +1348,85 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_td_commit(lpx_tableau s, const do
         }
         return;
     }
-    const int64_t r = ctrl->leave_r;
     const double *col = recv + win * msg + 2;
     const int64_t gi = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
     td_finish(s, r, best.i, col[r], (gi <= s.m) ? col[gi] : 0.0, best.v, -1.0, d, e, rowr);
+}
+
+// ---- lookahead for the partitioned dual loop: the proposal of pivot t+1 from the tableau as pivot t's K1 is about to
+// leave it.  Everything it needs is thin: the x_B column (leaving row r'), row r' and the reduced-cost row (ratio test)
+// and one column (the proposal), each formed from the old T, e and rowr with K1's own expressions, bit for bit.
+// entry (i, j) of the tableau after the pending update (K1's expressions, lpx_rank1.hpp)
+__device__ __forceinline__ double td_next_entry(const lpx_tableau &s, int64_t i, int64_t j, int64_t r, int64_t unit, const double *e,
+                                                const double *rowr)
+{
+    if (j == unit) return s.slot_var ? e[i] : ((i == r) ? 1.0 : 0.0);
+    return (i == r) ? e[i] * rowr[j] : fma(e[i], rowr[j], s.T[i * s.ld + j]);
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_row_next(lpx_tableau s, Partials R, const double *e, const double *rowr)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const double v = (i < s.m) ? td_next_entry(s, i, s.n, s.ctrl->leave_r, -1, e, rowr) : LPX_INF;
+    const double mn = block_min(v, red);
+    const int64_t first = block_imin((i < s.m && v < 0.0) ? i : LPX_NOIDX, red);
+    if (threadIdx.x == 0) {
+        R.v0[blockIdx.x] = mn;
+        R.i0[blockIdx.x] = first;
+    }
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_ratio_next(lpx_tableau s, Partials R, int64_t nrow, Partials P, int64_t strip,
+                                                            const double *e, const double *rowr, double *pend)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const double mn = combine_min(R.v0, nrow, red);
+    const int64_t r2 = combine_imin(R.i0, nrow, red);
+    const bool opt = lpx_is_optimal_min(mn); // dual_solvers.py:52-54
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pend[0] = (double)(opt ? 0 : r2);
+        pend[1] = opt ? 1.0 : 0.0;
+        pend[2] = mn;
+    }
+    if (opt) return;
+    const int64_t r = s.ctrl->leave_r, unit = t_unit_col(s);
+    const int64_t c0 = (int64_t)blockIdx.x * strip;
+    const int64_t c1 = (blockIdx.x == gridDim.x - 1) ? s.n : c0 + strip; // the last strip may be folded (lpx_rank1.hpp)
+    VI best{LPX_INF, LPX_NOIDX};
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += LPX_BLOCK) {
+        // basic columns count as 0 (dual_solvers.py:38-39; var_state already reflects the pending pivot)
+        const double row = (!s.slot_var && s.var_state[j] == LPX_VS_BASIC) ? 0.0 : td_next_entry(s, r2, j, r, unit, e, rowr);
+        const double rc = td_next_entry(s, s.m, j, r, unit, e, rowr);
+        const double th = lpx_dsd(rc, row, false); // never the first iteration
+        if (vi_less(th, t_var(s, j), best.v, best.i)) { best.v = th; best.i = t_var(s, j); }
+    }
+    best = block_argmin(best, red);
+    if (threadIdx.x == 0) {
+        P.v0[blockIdx.x] = best.v;
+        P.i0[blockIdx.x] = best.i;
+    }
+}
+__global__ __launch_bounds__(LPX_BLOCK) void k_td_propose_next(lpx_tableau s, Partials P, int64_t nprice, const double *e,
+                                                              const double *rowr, const double *pend, double *sendbuf)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    if (pend[1] != 0.0) { // optimal after the pending pivot: the next commit stops before it looks at the proposals
+        if (i == 0) {
+            sendbuf[0] = LPX_INF;
+            sendbuf[1] = (double)LPX_NOIDX;
+        }
+        if (i <= s.m) sendbuf[2 + i] = 0.0;
+        return;
+    }
+    const VI t = combine_argmin(P.v0, P.i0, nprice, red);
+    if (i == 0) {
+        sendbuf[0] = t.v;
+        sendbuf[1] = (double)t.i;
+    }
+    if (i <= s.m) sendbuf[2 + i] = td_next_entry(s, i, t_slot(s, t.i), s.ctrl->leave_r, t_unit_col(s), e, rowr);
 }
 
 static void td_launch_select(const lpx_tableau *s, const TabWs &w, const Rank1Plan &p, hipStream_t st)
@@ -1392,8 +1485,37 @@ extern "C" int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvb
     hipStream_t st = (hipStream_t)stream;
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     hipLaunchKernelGGL(k_td_commit, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks,
-                       lpx_tableau_msg_len(s->m), w.d, w.e, w.rowr);
+                       lpx_tableau_msg_len(s->m), w.d, w.e, w.rowr, (const double *)nullptr);
     t_launch_update(s, w, plan, st);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// The same pivot in two halves, for the loop that overlaps the exchange of pivot t+1 with the update of pivot t (see
+// lpx_tableau_commit_begin).  adopt != 0: the leaving row of this pivot was decided by the previous call's lookahead
+// (sendbuf_next != NULL there) instead of lpx_tableau_dual_propose.  sendbuf_next != NULL: also this rank's proposal for
+// the next pivot.  The update itself is lpx_tableau_commit_update.
+extern "C" int lpx_tableau_dual_commit_begin(const lpx_tableau *s, const double *recvbuf, int64_t nranks, int adopt,
+                                             double *sendbuf_next, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
+    LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
+    hipLaunchKernelGGL(k_td_commit, dim3((unsigned)lpx_cdiv(t_prep_len(s), LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, recvbuf, nranks,
+                       lpx_tableau_msg_len(s->m), w.d, w.e, w.rowr, adopt ? (const double *)w.pend : (const double *)nullptr);
+    if (sendbuf_next != nullptr) {
+        const int64_t nrow = lpx_cdiv(s->m, LPX_BLOCK), strip = 2 * (int64_t)plan.threads * plan.vpt;
+        hipLaunchKernelGGL(k_td_row_next, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, st, *s, w.ratio, (const double *)w.e,
+                           (const double *)w.rowr);
+        hipLaunchKernelGGL(k_td_ratio_next, dim3(plan.grid.x), dim3(LPX_BLOCK), 0, st, *s, w.ratio, nrow, w.price, strip,
+                           (const double *)w.e, (const double *)w.rowr, w.pend);
+        hipLaunchKernelGGL(k_td_propose_next, dim3((unsigned)lpx_cdiv(s->m + 1, LPX_BLOCK)), dim3(LPX_BLOCK), 0, st, *s, w.price,
+                           (int64_t)plan.grid.x, (const double *)w.e, (const double *)w.rowr, (const double *)w.pend, sendbuf_next);
+    }
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

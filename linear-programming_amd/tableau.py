@@ -101,7 +101,7 @@ class TableauEngine:
 
     CHUNK = 64
     FIRST_CHUNK = 16
-    #: column-partitioned primal loop: overlap the exchange of pivot t+1 with the update of pivot t
+    #: column-partitioned loops (primal and dual): overlap the exchange of pivot t+1 with the update of pivot t
     LOOKAHEAD = os.environ.get("LPX_TABLEAU_LOOKAHEAD", "1") != "0"
     #: largest tableau (bytes) that gets the second buffer of the single-launch chain
     FUSED_MAX_BYTES = int(os.environ.get("LPX_TABLEAU_FUSED_MAX_MB", "256")) << 20
@@ -234,13 +234,31 @@ class TableauEngine:
             _lib.check(f(C.byref(self.s), int(iters), st))
             return
         ex = self.exchange
-        if self.dual:
-            for it in range(int(iters)):
-                _lib.check(self.lib.lpx_tableau_dual_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))
-                ex.all_gather()
-                _lib.check(self.lib.lpx_tableau_dual_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
-            return
         iters = int(iters)
+        if self.dual:
+            if not self.LOOKAHEAD:
+                for it in range(iters):
+                    _lib.check(self.lib.lpx_tableau_dual_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))
+                    ex.all_gather()
+                    _lib.check(self.lib.lpx_tableau_dual_commit(C.byref(self.s), ex.recvbuf.data_ptr(), self.nranks, st))
+                return
+            # lookahead, as for the primal loop below: the leaving row and the proposal of pivot t+1 are formed from the
+            # old tableau, e and the old pivot row before pivot t's update is launched (lpx_tableau_dual_commit_begin)
+            if iters <= 0:
+                return
+            cur = 0
+            _lib.check(self.lib.lpx_tableau_dual_propose(C.byref(self.s), ex.sendbufs[cur].data_ptr(), st))
+            ex.all_gather(cur)
+            for it in range(iters):
+                nxt = cur ^ 1
+                last = it + 1 == iters
+                _lib.check(self.lib.lpx_tableau_dual_commit_begin(C.byref(self.s), ex.recvbufs[cur].data_ptr(), self.nranks,
+                                                                  int(it > 0), None if last else ex.sendbufs[nxt].data_ptr(), st))
+                work = None if last else ex.all_gather_async(nxt)
+                _lib.check(self.lib.lpx_tableau_commit_update(C.byref(self.s), st))
+                ex.wait(work)
+                cur = nxt
+            return
         if not self.LOOKAHEAD:
             for it in range(iters):
                 # the update kernel of the previous pivot leaves the pricing partials behind; only the first pivot of a

@@ -124,14 +124,91 @@ def numpy_rank_dual(c, A, b, basis, rank, world, ex, maxiters):
     return log, basis, T[:m, nl].copy(), "running"
 
 
+def numpy_rank_dual_ahead(c, A, b, basis, rank, world, ex, maxiters):
+    """The same with the lookahead ordering of TableauEngine.enqueue (lpx_tableau_dual_commit_begin / _commit_update): the
+    leaving row and the proposal of pivot t+1 are formed, and gathered into the OTHER slot, before pivot t's update is
+    applied to the carried tableau; the decision is adopted when pivot t+1 begins."""
+    c32, A32, b32 = O.preprocess(c, A, b)
+    m, n = A32.shape
+    j0, j1 = column_range(n, rank, world)
+    nl = j1 - j0
+    basis = np.array(basis, dtype=np.int64)
+    inv32 = np.linalg.inv(A32[:, basis])
+    T = np.zeros((m + 1, nl + 1))
+    T[:m, :nl] = (inv32 @ A32)[:, j0:j1]
+    T[:m, nl] = inv32 @ b32
+    T[m, :nl] = (c32 - c32[basis] @ inv32 @ A32)[j0:j1]
+    isbasic = np.zeros(n, dtype=bool)
+    isbasic[basis] = True
+    T[m, :nl][isbasic[j0:j1]] = 0.0
+
+    def propose(Tv, f32):  # (optimal?, leaving row, message) from a tableau view
+        xB = Tv[:m, nl]
+        mn = xB.min()
+        if mn >= 0 or abs(mn) <= 1e-8:
+            return True, 0, np.zeros(ex.msg)
+        r = int(np.flatnonzero(xB < 0)[0])
+        row = np.where(isbasic[j0:j1], 0.0, Tv[r, :nl])
+        rc = Tv[m, :nl]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if f32:
+                th = np.where(row < 0, ((-rc.astype(np.float32)) / row.astype(np.float32)).astype(np.float64), np.inf)
+            else:
+                th = np.where(row < 0, (-rc) / row, np.inf)
+        send = np.zeros(ex.msg)
+        k = int(np.argmin(th)) if nl else 0
+        send[0] = th[k] if nl else np.inf
+        send[1] = j0 + k
+        if nl:
+            send[2:2 + m + 1] = Tv[:, k]
+        return False, r, send
+
+    log = []
+    cur = 0
+    opt, r, send = propose(T, True)
+    ex.sendbufs[cur].copy_(torch.from_numpy(send))
+    ex.all_gather(cur)
+    pend = (opt, r)
+    for it in range(maxiters):
+        opt, r = pend  # adopted at the start of the pivot (k_td_commit)
+        if opt:
+            return log, basis, T[:m, nl].copy(), "optimal"
+        recv = ex.recvbufs[cur].numpy().reshape(world, ex.msg)
+        if np.all(np.isinf(recv[:, 0])):
+            return log, basis, T[:m, nl].copy(), "dual_unbounded"
+        win = min(range(world), key=lambda g: (recv[g, 0], recv[g, 1]))
+        j = int(recv[win, 1])
+        d = recv[win, 2:2 + m + 1].copy()
+        e = (-d) / d[r]
+        e[r] = 1.0 / d[r]
+        log.append([r, j, int(basis[r])])
+        isbasic[basis[r]] = False
+        isbasic[j] = True
+        basis[r] = j
+        # what the update is about to write (the device forms only the thin pieces it needs of it: td_next_entry)
+        Tn = O.rank1_update(np.ascontiguousarray(T), r, e)
+        if j0 <= j < j1:
+            Tn[:, j - j0] = 0.0
+            Tn[r, j - j0] = 1.0
+        nxt = cur ^ 1
+        if it + 1 < maxiters:
+            pend = propose(Tn, False)[:2]
+            ex.sendbufs[nxt].copy_(torch.from_numpy(propose(Tn, False)[2]))
+            ex.all_gather(nxt)  # travels while the update runs
+        T = Tn  # lpx_tableau_commit_update
+        cur = nxt
+    return log, basis, T[:m, nl].copy(), "running"
+
+
 def main_dual(mode, m, n, seed, maxiters):
     rank, world = dist.get_rank(), dist.get_world_size()
     c, A, b, basis = problems.gen_dual(m, n, seed)
     want = O.OracleTableau(c, A, b, basis, kind="dual", log_cap=maxiters + 1).solve(maxiters)
     assert len(want.log) > 3
-    if mode == "cpu-dual":
+    if mode in ("cpu-dual", "cpu-ahead-dual"):
         ex = ProposalExchange(dist.group.WORLD, m + 3 + ((m + 3) % 2), "cpu")
-        log, bas, xB, how = numpy_rank_dual(c, A, b, basis, rank, world, ex, maxiters)
+        model = numpy_rank_dual if mode == "cpu-dual" else numpy_rank_dual_ahead
+        log, bas, xB, how = model(c, A, b, basis, rank, world, ex, maxiters)
         assert log == want.log.tolist(), f"rank {rank}: pivot sequence differs"
         assert bas.tolist() == want.basis.tolist() and (how == "optimal") == (want.status == O.OPTIMAL)
     else:

@@ -57,7 +57,24 @@ def test_dual_protocol_cpu_gloo(nproc, m, n):
     _run("cpu-dual", nproc, m, n, 1, 100000)
 
 
+@pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
+def test_dual_protocol_lookahead_cpu_gloo(nproc, m, n):
+    """The two-slot ordering of the dual loop with lookahead (decide and gather pivot t+1, then apply pivot t)."""
+    _run("cpu-ahead-dual", nproc, m, n, 1, 100000)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
 def test_dual_product_path_two_ranks_one_gpu(nproc, m, n):
     _run("gpu-dual", nproc, m, n, 2, 100000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"LPX_TABLEAU_LOOKAHEAD": "0"}, {"LPX_TABLEAU_CONDENSED": "0"},
+                                 {"LPX_TABLEAU_CONDENSED": "0", "LPX_TABLEAU_LOOKAHEAD": "0"}],
+                         ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
+def test_dual_product_path_lookahead_and_layouts(env):
+    """The default run above decides the leaving row and the proposal of pivot t+1 before pivot t's update is launched
+    (lpx_tableau_dual_commit_begin) and gathers them while it runs; here the plain propose -> all-gather -> commit loop and
+    the full (every column) layout, with and without lookahead.  All must give the oracle's pivot sequence."""
+    _run("gpu-dual", 2, 64, 128, 2, 100000, **env)
