@@ -72,7 +72,7 @@ struct TabBatchArgs {
 // DUAL: the dual simplex rules (dual_solvers.py:47-108) on the same carried state; the starting basis is then the slack
 // block with +-1 on its diagonal (-1 where preprocessing flipped a row with b < 0), x_B = B^-1 b may be negative.
 template <int MR, bool DUAL>
-__global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
+__global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchArgs a)
 {
     __shared__ double dcol[TB_MAX + 2];
     __shared__ double xs[2 * TB_MAX];
@@ -86,26 +86,42 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
     const float *A = a.A + lp * a.m * a.na;
 
     const bool from_T0 = !DUAL && a.T0 != nullptr; // wave-uniform: the caller supplies the starting tableau (A, b unused)
+    // Loads are unconditional, from clamped (always valid) addresses, and selected afterwards: a load under a lane
+    // condition compiles to a branch with its own wait, i.e. MR global-memory round trips one after the other
+    const int tc = col ? t : 0, tr = row ? t : 0;
     double x[MR];
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        // B^-1 of a +-identity basis is itself: row i of B^-1 A is row i of A times B_ii (exact)
-        const double sg = (DUAL && i < m) ? (double)A[(int64_t)i * na + k + i] : 1.0;
-        x[i] = (col && i < m && !from_T0) ? sg * (double)A[(int64_t)i * na + t] : 0.0;
-    }
-    double rc = (col && !from_T0) ? (double)a.c[lp * na + t] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
-    double xb = (row && !from_T0) ? (double)a.b[lp * m + t] : 0.0;
-    if (DUAL && row) xb *= (double)A[(int64_t)t * na + k + t];
+    double rc, xb;
     int64_t var = col ? (int64_t)t : LPX_NOIDX; // variable held by this lane's column slot
     int64_t bas = row ? (int64_t)(k + t) : -1;  // basis[t]
-    if (from_T0) {
-        const float *T0 = a.T0 + lp * a.m * k;
+    if (!from_T0) {
+        float av[MR], sv[MR];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)T0[(int64_t)i * k + t] : 0.0;
-        rc = col ? (double)a.rc0[lp * k + t] : 0.0;
-        xb = row ? (double)a.xb0[lp * m + t] : 0.0;
-        var = col ? a.var0[lp * k + t] : LPX_NOIDX;
-        bas = row ? a.basis[lp * m + t] : -1;
+        for (int i = 0; i < MR; ++i) {
+            const int ri = i < m ? i : m - 1;
+            av[i] = A[(int64_t)ri * na + tc];
+            // B^-1 of a +-identity basis is itself: row i of B^-1 A is row i of A times B_ii (exact)
+            sv[i] = DUAL ? A[(int64_t)ri * na + k + ri] : 1.f;
+        }
+        const float cv = a.c[lp * na + tc], bv = a.b[lp * m + tr];
+        const float sb = DUAL ? A[(int64_t)tr * na + k + tr] : 1.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)sv[i] * (double)av[i] : 0.0;
+        rc = col ? (double)cv : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+        xb = row ? (double)bv : 0.0;
+        if (DUAL && row) xb *= (double)sb;
+    } else {
+        const float *T0 = a.T0 + lp * a.m * k;
+        float av[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) av[i] = T0[(int64_t)(i < m ? i : m - 1) * k + tc];
+        const float cv = a.rc0[lp * k + tc], bv = a.xb0[lp * m + tr];
+        const int64_t v0 = a.var0[lp * k + tc], b0 = a.basis[lp * m + tr];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) x[i] = (col && i < m) ? (double)av[i] : 0.0;
+        rc = col ? (double)cv : 0.0;
+        xb = row ? (double)bv : 0.0;
+        var = col ? v0 : LPX_NOIDX;
+        bas = row ? b0 : -1;
     }
     for (int j = t; j < n; j += 64) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
 
@@ -183,7 +199,9 @@ __global__ __launch_bounds__(64) void k_batched_tab(TabBatchArgs a)
         // Two special cases take their addend from -0.0: the pivot row in every lane -- fma(e_r, row_r, -0.0) is the plain
         // product -- and every row of the entering lane, whose multiplicand is 1: fma(e_i, 1, -0.0) is e_i itself, bit for
         // bit.  Neither costs a select per element: the entering lane clears its column under its own exec mask, and only
-        // the 8 rows around the pivot row (a scalar branch) run selects.  The update is then 2 readlanes + 1 fma per row.
+        // the 8 rows around the pivot row (a scalar branch) run selects.  The update is then 2 readlanes + 1 fma per row
+        // (e as broadcast ds_read_b128, one per two rows, is slower: 718 against 790 M pivots/s at 64 x 128 -- every LDS
+        // instruction costs a lone wave ~13 cycles of issue and the four SIMDs share one LDS pipe).
         const bool mine = t == jl;
         const double prs = mine ? 1.0 : pr;
         if (mine) {
@@ -372,10 +390,18 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
     const float *A = a.A + lp * a.m * a.na;
 
     double x[MRL];
+    double rc, xb;
+    { // unconditional loads from clamped addresses, selected afterwards (see k_batched_tab)
+        const int tc = col ? cs : 0, tr = row ? t : 0;
+        float av[MRL];
 #pragma unroll
-    for (int i = 0; i < MRL; ++i) x[i] = (col && r0 + i < m) ? (double)A[(int64_t)(r0 + i) * na + cs] : 0.0;
-    double rc = col ? (double)a.c[lp * na + cs] : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
-    double xb = row ? (double)a.b[lp * m + t] : 0.0;
+        for (int i = 0; i < MRL; ++i) av[i] = A[(int64_t)(r0 + i < m ? r0 + i : m - 1) * na + tc];
+        const float cv = a.c[lp * na + tc], bv = a.b[lp * m + tr];
+#pragma unroll
+        for (int i = 0; i < MRL; ++i) x[i] = (col && r0 + i < m) ? (double)av[i] : 0.0;
+        rc = col ? (double)cv : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+        xb = row ? (double)bv : 0.0;
+    }
     int var = col ? cs : 0x7FFFFFFF; // variable held by this lane's column slot
     int bas = row ? k + t : -1;      // basis[t]
     for (int j = t; j < n; j += NT) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
