@@ -444,7 +444,8 @@ def test_tableau_without_nonbasic_columns_falls_back_to_the_full_layout():
 
 @pytest.mark.parametrize("m,n", [(4, 8), (5, 12), (16, 32), (37, 100), (40, 104), (64, 128), (61, 125), (64, 70),
                                  (80, 170), (96, 192), (64, 256), (70, 80), (65, 130), (128, 256), (100, 340), (30, 200),
-                                 (128, 384)])
+                                 (128, 384), (65, 66), (2, 200), (128, 129), (256, 300), (129, 257), (200, 300), (3, 131),
+                                 (256, 384)])
 def test_batched_tableau_kernel_bit_identical_to_the_tableau_oracle(m, n):
     """lpx_batched_tableau_solve (condensed tableau in registers, one wave per LP): per LP the pivot log, x, cost, basis and
     iters of the oracle's tableau loop, bit for bit, on full solves and on solves cut off by maxiters; the revised-form
@@ -503,7 +504,16 @@ def test_batched_tableau_kernel_reference_sequences_and_unbounded():
     assert sol.raw["status"].tolist() == [_lib.OPTIMAL, _lib.PRIMAL_UNBOUNDED, _lib.OPTIMAL]
     assert np.array_equal(out[0].x, res[0].x) and np.array_equal(out[2].x, res[2].x)
     with pytest.raises(ValueError):
-        BatchedTableauSolver(*[np.stack([p[k] for p in [gen.gen_primal(130, 260, 0)]]) for k in range(4)])  # m > 128
+        BatchedTableauSolver(*[np.stack([p[k] for p in [gen.gen_primal(130, 260, 0)]]) for k in range(4)])  # 4 x 3 waves
+    # the same in the multi-wave kernel (80 x 170: four waves per LP)
+    probs = [gen.gen_primal(80, 170, s) for s in range(3)]
+    c, A, b, basis = [np.stack([p[k] for p in probs]) for k in range(4)]
+    ref = BatchedTableauSolver(c, A, b, basis).solve(100000)
+    A[1, :, :90] *= -1
+    sol = BatchedTableauSolver(c, A, b, basis)
+    out = sol.solve(100000)
+    assert sol.raw["status"].tolist() == [_lib.OPTIMAL, _lib.PRIMAL_UNBOUNDED, _lib.OPTIMAL]
+    assert np.array_equal(out[0].x, ref[0].x) and np.array_equal(out[2].x, ref[2].x)
 
 
 @pytest.mark.parametrize("m,k", [(8, 8), (24, 40), (64, 64), (37, 60), (80, 90), (64, 192), (128, 128)])
