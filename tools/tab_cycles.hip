@@ -47,8 +47,12 @@ static void run(int64_t B, int64_t m, int64_t n)
     hipFree(dA); hipFree(db); hipFree(dc); hipFree(dbasis); hipFree(diters); hipFree(dpiv); hipFree(dx); hipFree(dcost); hipFree(dstatus);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) { // one shape at full residency: the run to put under rocprofv3 --pmc
+        run(12288, 64, 128);
+        return 0;
+    }
     for (int64_t B : {1024, 3072, 12288}) run(B, 64, 128);
     for (int64_t B : {512, 1536, 6144}) run(B, 80, 170);
     for (int64_t B : {256, 768, 3072}) run(B, 64, 256);
