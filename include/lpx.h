@@ -365,14 +365,14 @@ int lpx_batched_tableau_waves(int64_t m, int64_t k);
 /* lpx_batched_tableau_solve from ANY primal feasible starting basis (primal_solvers.py:37-53).  The caller forms the
  * starting tableau with the reference's float32 expressions and passes it: T0 = (inv(A_B) A)[:, nonbasic] (m x k per LP,
  * k = n - m), rc0 = its reduced costs (k), xb0 = inv(A_B) b (m), var0 = the variable of every column (k), basis (m, input
- * and output); c (n per LP) is used for the cost of the result only. */
+ * and output); c (n per LP) is used for the cost of the result only.  Shapes as lpx_batched_tableau_solve. */
 int lpx_batched_tableau_solve_from(int64_t batch, int64_t m, int64_t n, const float *T0, const float *rc0, const float *xb0,
                                    const int64_t *var0, const float *c, int64_t *basis, double *x, double *cost,
                                    int32_t *status, int64_t *iters, int64_t *pivots, int64_t maxiters, int64_t *log,
                                    int64_t log_cap, void *stream);
 /* DualRevisedSimplexSolver per LP (dual_solvers.py:82-120) with the same carried state.  A, b as preprocessing.py:6-15 leaves
  * them (rows with b < 0 flipped): the slack block then has +-1 on its diagonal and is the starting basis (B^-1 = B), its
- * costs are 0 and c >= 0 elsewhere (dual feasible, :14-16) -- the caller's checks.  m <= 64, n - m <= 64. */
+ * costs are 0 and c >= 0 elsewhere (dual feasible, :14-16) -- the caller's checks.  Shapes as lpx_batched_tableau_solve. */
 int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t n, const float *A, const float *b, const float *c,
                                    int64_t *basis, double *x, double *cost, int32_t *status, int64_t *iters, int64_t *pivots,
                                    int64_t maxiters, int64_t *log, int64_t log_cap, void *stream);

@@ -140,7 +140,8 @@ class BatchedTableauSolver(BatchedPrimalSolver):
     reference's constructor state and CARRIED for the whole solve, whereas the reference recomputes ``inv64 @ A`` in
     float64 from its second pivot on: x and cost then agree with the reference and with the revised-form kernel to
     float32 accuracy only (about 1e-5 relative), and a reduced cost within ~1e-7 of zero may pick another pivot.  Use
-    ``BatchedPrimalSolver`` where 1e-9 is needed from a general start (``solve_many`` does)."""
+    ``BatchedPrimalSolver`` where 1e-9 is needed from a general start (``solve_many`` does).  Same shape limits for
+    both starts."""
 
     def __init__(self, c, A, b, basis, log_cap=0):
         super().__init__(c, A, b, basis, log_cap=log_cap)  # preprocessing, feasibility check (primal_solvers.py:41-53)
@@ -152,8 +153,6 @@ class BatchedTableauSolver(BatchedPrimalSolver):
         self.start = None
         slack = (self.Binv0 is None and np.array_equal(basis, np.broadcast_to(np.arange(k, self.n), (self.B, self.m)))
                  and not np.any(c32[:, k:] != 0))
-        if not slack and (self.m > 64 or k > 64):
-            raise ValueError("BatchedTableauSolver from a general starting basis: m <= 64 and n - m <= 64")
         if not slack:
             # any other start: the reference's float32 constructor state (:37-38, :64) carried as a condensed tableau,
             # formed per LP on the host with the reference's own NumPy expressions
@@ -200,7 +199,8 @@ class BatchedTableauSolver(BatchedPrimalSolver):
 class BatchedDualTableauSolver(BatchedDualSolver):
     """``DualRevisedSimplexSolver`` per LP with the condensed tableau as carried state (``lpx_batched_tableau_dual_solve``).
     Starting basis: the slack block, +-identity after preprocessing flipped the rows with b < 0, with zero costs; dual
-    feasibility is checked per LP as in ``BatchedDualSolver``.  Bit-identical to the oracle's dual tableau loop."""
+    feasibility is checked per LP as in ``BatchedDualSolver``.  Bit-identical to the oracle's dual tableau loop.  Shapes as
+    for ``BatchedTableauSolver``: one wave per LP up to 64 x 64 tableau slots, a grid of up to eight waves beyond."""
 
     def __init__(self, c, A, b, basis, log_cap=0):
         super().__init__(c, A, b, basis, log_cap=log_cap)
@@ -212,8 +212,8 @@ class BatchedDualTableauSolver(BatchedDualSolver):
                 or np.count_nonzero(blk) != self.B * self.m or not np.all(np.abs(diag) == 1.0)
                 or np.any(self.c.cpu().numpy()[:, k:] != 0)):
             raise ValueError("BatchedDualTableauSolver starts from the slack basis (+-identity columns n-m..n-1, zero costs)")
-        if self.m > 64 or k > 64:
-            raise ValueError("BatchedDualTableauSolver: m <= 64 and n - m <= 64")
+        if not self.lib.lpx_batched_tableau_waves(self.m, k):
+            raise ValueError("BatchedDualTableauSolver: m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128")
 
     def enqueue(self, maxiters):
         _lib.check(self.lib.lpx_batched_tableau_dual_solve(

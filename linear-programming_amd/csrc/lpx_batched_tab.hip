@@ -255,11 +255,12 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
 }
 
 extern "C" int lpx_batched_tableau_waves(int64_t m, int64_t k);
+template <bool DUAL>
 static int tab_launch_multi(const TabBatchArgs &a, void *stream);
 template <bool DUAL>
 static int tab_launch(const TabBatchArgs &a, void *stream)
 {
-    if (!DUAL && a.T0 == nullptr && (a.m > TB_MAX || a.n - a.m > TB_MAX)) return tab_launch_multi(a, stream);
+    if (a.m > TB_MAX || a.n - a.m > TB_MAX) return tab_launch_multi<DUAL>(a, stream);
     const dim3 grid((unsigned)a.batch), block(64);
     hipStream_t st = (hipStream_t)stream;
     if (a.m <= 16) hipLaunchKernelGGL((k_batched_tab<16, DUAL>), grid, block, 0, st, a);
@@ -313,7 +314,7 @@ extern "C" int lpx_batched_tableau_dual_solve(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
     LPX_REQUIRE(A && b && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
-    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    LPX_REQUIRE(lpx_batched_tableau_waves(m, n - m) != 0, "m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128 (up to eight waves per LP)");
     return tab_launch<true>(TabBatchArgs{batch, m, n, A, b, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
@@ -328,7 +329,7 @@ extern "C" int lpx_batched_tableau_solve_from(int64_t batch, int64_t m, int64_t 
     LPX_REQUIRE(batch > 0 && m > 0 && n > m && maxiters >= 0, "bad sizes");
     LPX_REQUIRE(T0 && rc0 && xb0 && var0 && c && basis && x && cost && status && iters && pivots, "null pointer");
     LPX_REQUIRE(log == nullptr || log_cap > 0, "log without capacity");
-    LPX_REQUIRE(m <= TB_MAX && n - m <= TB_MAX, "m <= 64 and n - m <= 64 (one lane per row and per nonbasic column)");
+    LPX_REQUIRE(lpx_batched_tableau_waves(m, n - m) != 0, "m <= 128 with n - m <= 256, or m <= 256 with n - m <= 128 (up to eight waves per LP)");
     // A and b are not read in this mode: T0 / xb0 stand in so that the unused pointers stay valid
     return tab_launch<false>(TabBatchArgs{batch, m, n, T0, xb0, c, basis, x, cost, status, iters, pivots, maxiters, log, log_cap, n, T0, rc0,
                                           xb0, var0},
@@ -365,7 +366,17 @@ struct Tab2Ratio {
     int row, bas, anypos, pad;
 };
 
-template <int MRL, int RW, int CW>
+struct Tab2Row { // dual rules: a wave's first row with x_B < 0
+    double xb;
+    int row, bas, anyneg, anyopen;
+};
+struct Tab2Theta { // dual rules: a column group's first argmin of theta, by variable id
+    double th;
+    int var, slot, anyrow, pad;
+};
+
+// DUAL: the dual simplex rules (dual_solvers.py:47-108) on the same carried state, as in k_batched_tab.
+template <int MRL, int RW, int CW, bool DUAL>
 __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab_grid(TabBatchArgs a)
 {
     constexpr int NW = RW * CW, NT = 64 * NW, M = RW * MRL, NRW = (M + 63) / 64;
@@ -377,6 +388,8 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
     __shared__ float cf[TBG_MAX_N];
     __shared__ Tab2Price shp[CW];
     __shared__ Tab2Ratio shr[NRW];
+    __shared__ Tab2Row shd[NRW];
+    __shared__ Tab2Theta shq[CW];
     TB_STAMP_BEGIN
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -388,22 +401,45 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
     const bool col = cs < k, row = t < m;
     const int na = (int)a.na;
     const float *A = a.A + lp * a.m * a.na;
+    const bool from_T0 = !DUAL && a.T0 != nullptr; // uniform: the caller supplies the starting tableau (A, b unused)
 
     double x[MRL];
     double rc, xb;
-    { // unconditional loads from clamped addresses, selected afterwards (see k_batched_tab)
-        const int tc = col ? cs : 0, tr = row ? t : 0;
-        float av[MRL];
-#pragma unroll
-        for (int i = 0; i < MRL; ++i) av[i] = A[(int64_t)(r0 + i < m ? r0 + i : m - 1) * na + tc];
-        const float cv = a.c[lp * na + tc], bv = a.b[lp * m + tr];
-#pragma unroll
-        for (int i = 0; i < MRL; ++i) x[i] = (col && r0 + i < m) ? (double)av[i] : 0.0;
-        rc = col ? (double)cv : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
-        xb = row ? (double)bv : 0.0;
-    }
     int var = col ? cs : 0x7FFFFFFF; // variable held by this lane's column slot
     int bas = row ? k + t : -1;      // basis[t]
+    { // unconditional loads from clamped addresses, selected afterwards (see k_batched_tab)
+        const int tc = col ? cs : 0, tr = row ? t : 0;
+        float av[MRL], sv[MRL];
+        if (!from_T0) {
+#pragma unroll
+            for (int i = 0; i < MRL; ++i) {
+                const int ri = r0 + i < m ? r0 + i : m - 1;
+                av[i] = A[(int64_t)ri * na + tc];
+                // B^-1 of a +-identity basis is itself: row i of B^-1 A is row i of A times B_ii (exact)
+                sv[i] = DUAL ? A[(int64_t)ri * na + k + ri] : 1.f;
+            }
+            const float cv = a.c[lp * na + tc], bv = a.b[lp * m + tr];
+            const float sb = DUAL ? A[(int64_t)tr * na + k + tr] : 1.f;
+            rc = col ? (double)cv : 0.0; // basic costs are 0: rc = c - c_B B^-1 A = c
+            xb = row ? (double)bv : 0.0;
+            if (DUAL && row) xb *= (double)sb;
+        } else {
+            const float *T0 = a.T0 + lp * a.m * k;
+#pragma unroll
+            for (int i = 0; i < MRL; ++i) {
+                av[i] = T0[(int64_t)(r0 + i < m ? r0 + i : m - 1) * k + tc];
+                sv[i] = 1.f;
+            }
+            const float cv = a.rc0[lp * k + tc], bv = a.xb0[lp * m + tr];
+            const int64_t v0 = a.var0[lp * k + tc], b0 = a.basis[lp * m + tr];
+            rc = col ? (double)cv : 0.0;
+            xb = row ? (double)bv : 0.0;
+            var = col ? (int)v0 : 0x7FFFFFFF;
+            bas = row ? (int)b0 : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < MRL; ++i) x[i] = (col && r0 + i < m) ? (double)sv[i] * (double)av[i] : 0.0;
+    }
     for (int j = t; j < n; j += NT) cf[j] = j < na ? a.c[lp * na + j] : 0.f;
     if (t < 64) es[M + t] = 0.0; // the tail a whole-wave read of a short row group touches
 
@@ -412,67 +448,148 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
     int64_t counter = 0, pivots = 0;
     while (counter < a.maxiters) {
         counter += 1;
-        // ---- (A) pricing (primal_solvers.py:135-142)
-        if (rg == 0) {
-            const bool neg = col && rc < 0.0;
-            const int64_t mine_key = neg ? (((int64_t)var << 8) | cs) : INT64_MAX; // ids < 2^31, slots < 256
-            const int64_t kmin = wave_imin(mine_key);
-            const int anyn = __ballot(neg) != 0, anyo = __ballot(col && rc < -LPX_ATOL) != 0;
-            if (lane == 0) shp[cg] = Tab2Price{kmin, anyn, anyo};
-        }
-        __syncthreads();
-        int64_t key = INT64_MAX;
-        bool anyneg = false, anyopen = false;
+        int r, jv, jl, leaving;
+        double d, rcj, dr, xr, pr = 0.0;
+        bool mine;
+        if (!DUAL) {
+            // ---- (A) pricing (primal_solvers.py:135-142)
+            if (rg == 0) {
+                const bool neg = col && rc < 0.0;
+                const int64_t mine_key = neg ? (((int64_t)var << 8) | cs) : INT64_MAX; // ids < 2^31, slots < 256
+                const int64_t kmin = wave_imin(mine_key);
+                const int anyn = __ballot(neg) != 0, anyo = __ballot(col && rc < -LPX_ATOL) != 0;
+                if (lane == 0) shp[cg] = Tab2Price{kmin, anyn, anyo};
+            }
+            __syncthreads();
+            int64_t key = INT64_MAX;
+            bool anyneg = false, anyopen = false;
 #pragma unroll
-        for (int w = 0; w < CW; ++w) {
-            const Tab2Price p = shp[w];
-            key = p.key < key ? p.key : key;
-            anyneg = anyneg || p.anyneg;
-            anyopen = anyopen || p.anyopen;
-        }
-        if (!anyneg || !anyopen) { // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (:140-142)
-            status = LPX_OPTIMAL;
-            break;
-        }
-        const int jv = (int)(key >> 8), jl = (int)(key & 0xFF); // first negative index by variable id, and its slot
-        const bool mine = cs == jl;                               // one lane in every row group
-        // ---- (B) entering column (:149-152)
-        if (mine) {
+            for (int w = 0; w < CW; ++w) {
+                const Tab2Price p = shp[w];
+                key = p.key < key ? p.key : key;
+                anyneg = anyneg || p.anyneg;
+                anyopen = anyopen || p.anyopen;
+            }
+            if (!anyneg || !anyopen) { // optimal <=> min rc >= 0 or |min rc| <= 1e-8 (:140-142)
+                status = LPX_OPTIMAL;
+                break;
+            }
+            jv = (int)(key >> 8), jl = (int)(key & 0xFF); // first negative index by variable id, and its slot
+            mine = cs == jl;                               // one lane in every row group
+            // ---- (B) entering column (:149-152)
+            if (mine) {
 #pragma unroll
-            for (int i = 0; i < MRL; ++i) dcol[r0 + i] = x[i];
-            if (rg == 0) dcol[M] = rc;
-        }
-        __syncthreads();
-        const double d = row ? dcol[t] : 0.0;
-        const double rcj = dcol[M];
-        // ---- (C) ratio test (:154-167)
-        if (wave < NRW) {
-            const double th = row ? lpx_psd(xb, d, f32) : LPX_INF;
-            const double thmin = wave_min(th);
-            const unsigned long long who = __ballot(th == thmin); // rows ascend with the lane: first lane = np.argmin
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
-            const double xbs = tb_readlane(xb, src);
-            const int bs = __builtin_amdgcn_readlane(bas, src);
-            const int anypos = __ballot(row && d > 0.0) != 0;
-            if (lane == 0) shr[wave] = Tab2Ratio{thmin, xbs, wave * 64 + src, bs, anypos, 0};
-        }
-        __syncthreads();
-        Tab2Ratio best = shr[0];
+                for (int i = 0; i < MRL; ++i) dcol[r0 + i] = x[i];
+                if (rg == 0) dcol[M] = rc;
+            }
+            __syncthreads();
+            d = row ? dcol[t] : 0.0;
+            rcj = dcol[M];
+            // ---- (C) ratio test (:154-167)
+            if (wave < NRW) {
+                const double th = row ? lpx_psd(xb, d, f32) : LPX_INF;
+                const double thmin = wave_min(th);
+                const unsigned long long who = __ballot(th == thmin); // rows ascend with the lane: first lane = np.argmin
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+                const double xbs = tb_readlane(xb, src);
+                const int bs = __builtin_amdgcn_readlane(bas, src);
+                const int anypos = __ballot(row && d > 0.0) != 0;
+                if (lane == 0) shr[wave] = Tab2Ratio{thmin, xbs, wave * 64 + src, bs, anypos, 0};
+            }
+            __syncthreads();
+            Tab2Ratio best = shr[0];
 #pragma unroll
-        for (int w = 1; w < NRW; ++w) {
-            const Tab2Ratio q = shr[w];
-            const bool take = q.th < best.th; // strict: the earlier wave (lower rows) keeps ties
-            const int ap = best.anypos | q.anypos;
-            if (take) best = q;
-            best.anypos = ap;
+            for (int w = 1; w < NRW; ++w) {
+                const Tab2Ratio q = shr[w];
+                const bool take = q.th < best.th; // strict: the earlier wave (lower rows) keeps ties
+                const int ap = best.anypos | q.anypos;
+                if (take) best = q;
+                best.anypos = ap;
+            }
+            if (!best.anypos) { // max(d) <= 0 (:144-147)
+                status = LPX_PRIMAL_UNBOUNDED;
+                break;
+            }
+            r = __builtin_amdgcn_readfirstlane(best.row); // the same in every lane: make it a scalar
+            dr = dcol[r], xr = best.xb;
+            leaving = best.bas;
+        } else {
+            // ---- (A) leaving row = first x_B < 0; optimal iff min x_B >= 0 or |min| <= 1e-8 (dual_solvers.py:47-54)
+            if (wave < NRW) {
+                const unsigned long long nb = __ballot(row && xb < 0.0);
+                const int anyo = __ballot(row && xb < -LPX_ATOL) != 0;
+                const int src = nb ? __builtin_amdgcn_readfirstlane(__ffsll((long long)nb) - 1) : 0;
+                const double xbs = tb_readlane(xb, src);
+                const int bs = __builtin_amdgcn_readlane(bas, src);
+                if (lane == 0) shd[wave] = Tab2Row{xbs, wave * 64 + src, bs, nb != 0, anyo};
+            }
+            __syncthreads();
+            Tab2Row lead = shd[0];
+            bool anyopen = lead.anyopen != 0;
+#pragma unroll
+            for (int w = 1; w < NRW; ++w) {
+                const Tab2Row q = shd[w];
+                anyopen = anyopen || q.anyopen;
+                if (!lead.anyneg && q.anyneg) lead = q; // rows ascend with the wave: the first wave that has one
+            }
+            if (!lead.anyneg || !anyopen) {
+                status = LPX_OPTIMAL;
+                break;
+            }
+            r = __builtin_amdgcn_readfirstlane(lead.row);
+            xr = lead.xb;
+            leaving = lead.bas;
+            // ---- (B) the dual row B^-1[r,:] A (:37-38): each column's entry sits in the row group that holds row r
+            {
+                const int rr = r / MRL, rl = r - rr * MRL;
+                if (rg == rr) {
+                    switch (rl) {
+#define TB_GET(i) case (i): if constexpr ((i) < MRL) pr = x[(i) < MRL ? (i) : 0]; break;
+                        TB_ROWS(TB_GET)
+#undef TB_GET
+                    }
+                    prow[cs] = pr;
+                }
+                __syncthreads();
+                if (rg != rr) pr = prow[cs];
+            }
+            // ---- (C) ratio test over the columns: first argmin of (-rc_j) / row_j over row_j < 0, by variable id (:61-80)
+            if (rg == 0) {
+                const double th = col ? lpx_dsd(rc, pr, f32) : LPX_INF;
+                const double thmin = wave_min(th);
+                const int vmin = (int)wave_imin((th == thmin && col) ? (int64_t)var : (int64_t)0x7FFFFFFF);
+                const unsigned long long who = __ballot(col && var == vmin);
+                const int src = who ? __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1) : 0;
+                const int anyrow = __ballot(col && pr < 0.0) != 0;
+                if (lane == 0) shq[cg] = Tab2Theta{thmin, vmin, cg * 64 + src, anyrow, 0};
+            }
+            __syncthreads();
+            Tab2Theta best = shq[0];
+#pragma unroll
+            for (int w = 1; w < CW; ++w) {
+                const Tab2Theta q = shq[w];
+                const int ar = best.anyrow | q.anyrow;
+                if (q.th < best.th || (q.th == best.th && q.var < best.var)) best = q;
+                best.anyrow = ar;
+            }
+            if (!best.anyrow) { // min(row) >= 0 (:56-59)
+                status = LPX_DUAL_UNBOUNDED;
+                break;
+            }
+            jv = best.var;
+            jl = __builtin_amdgcn_readfirstlane(best.slot);
+            mine = cs == jl;
+            // ---- (D) entering column
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < MRL; ++i) dcol[r0 + i] = x[i];
+                if (rg == 0) dcol[M] = rc;
+            }
+            __syncthreads();
+            d = row ? dcol[t] : 0.0;
+            rcj = dcol[M];
+            dr = dcol[r];
         }
-        if (!best.anypos) { // max(d) <= 0 (:144-147)
-            status = LPX_PRIMAL_UNBOUNDED;
-            break;
-        }
-        const int r = __builtin_amdgcn_readfirstlane(best.row); // the same in every lane: make it a scalar
-        const double dr = dcol[r], xr = best.xb;
-        const int leaving = best.bas;
         // ---- (D) eta column (:236-244), x_B (:251-253), pivot row
         const double em = (-rcj) / dr; // eliminates the entering column's reduced cost
         if (wave < NRW) {
@@ -481,9 +598,8 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
             if (row) xb = (t == r) ? e * xr : fma(e, xr, xb);
         }
         const int rr = r / MRL, rl = r - rr * MRL;
-        double pr = 0.0;
-        if (rg == rr) {
-            switch (rl) { // this column's pivot-row entry; its addend becomes -0.0: fma(e_r, row_r, -0.0) is the plain product
+        if (!DUAL && rg == rr) { // this column's pivot-row entry (the dual rules fetched it for their ratio test)
+            switch (rl) {
 #define TB_GET(i) case (i): if constexpr ((i) < MRL) pr = x[(i) < MRL ? (i) : 0]; break;
                 TB_ROWS(TB_GET)
 #undef TB_GET
@@ -491,7 +607,7 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
             prow[cs] = pr;
         }
         __syncthreads();
-        if (rg != rr) pr = prow[cs];
+        if (!DUAL && rg != rr) pr = prow[cs];
         // the entering slot receives the eta column itself: multiplicand 1, addends -0.0 (fma(e_i, 1, -0.0) = e_i bit for bit)
         const double prs = mine ? 1.0 : pr;
         if (mine) {
@@ -555,26 +671,31 @@ extern "C" int lpx_batched_tableau_waves(int64_t m, int64_t k)
     return rw * cw <= 8 ? rw * cw : 0;
 }
 
+template <bool DUAL>
 static int tab_launch_multi(const TabBatchArgs &a, void *stream)
 {
     const int m = (int)a.m, k = (int)(a.n - a.m);
     const int rw = m <= 64 ? 1 : m <= 128 ? 2 : 4, cw = (k + 63) / 64;
-    const int per = (m + rw - 1) / rw, mrl = per <= 16 ? 16 : (per + 7) / 8 * 8; // rows per lane, in steps of 8
+    const int per = (m + rw - 1) / rw;
+    // rows per lane: in steps of 8 for the primal rules (every shape of a batch sweep gets a close fit), of 16 for the dual
+    const int mrl = per <= 16 ? 16 : DUAL ? (per + 15) / 16 * 16 : (per + 7) / 8 * 8;
     const dim3 grid((unsigned)a.batch), block((unsigned)(64 * rw * cw));
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
 #define TBG_GO(MRLv, RWv, CWv)                                                                                          \
     if (!done && mrl == MRLv && rw == RWv && cw == CWv) {                                                              \
-        hipLaunchKernelGGL((k_batched_tab_grid<MRLv, RWv, CWv>), grid, block, 0, st, a);                               \
+        hipLaunchKernelGGL((k_batched_tab_grid<MRLv, RWv, CWv, DUAL>), grid, block, 0, st, a);                         \
         done = true;                                                                                                   \
     }
-#define TBG_ROWSN(RWv, CWv) TBG_GO(40, RWv, CWv) TBG_GO(48, RWv, CWv) TBG_GO(56, RWv, CWv) TBG_GO(64, RWv, CWv)
-#define TBG_ROWS1(CWv) TBG_GO(16, 1, CWv) TBG_GO(24, 1, CWv) TBG_GO(32, 1, CWv) TBG_ROWSN(1, CWv)
+#define TBG_ODD(MRLv, RWv, CWv) if constexpr (!DUAL) { TBG_GO(MRLv, RWv, CWv) }
+#define TBG_ROWSN(RWv, CWv) TBG_ODD(40, RWv, CWv) TBG_GO(48, RWv, CWv) TBG_ODD(56, RWv, CWv) TBG_GO(64, RWv, CWv)
+#define TBG_ROWS1(CWv) TBG_GO(16, 1, CWv) TBG_ODD(24, 1, CWv) TBG_GO(32, 1, CWv) TBG_ROWSN(1, CWv)
     TBG_ROWS1(2) TBG_ROWS1(3) TBG_ROWS1(4)
     TBG_ROWSN(2, 1) TBG_ROWSN(2, 2) TBG_ROWSN(2, 3) TBG_ROWSN(2, 4)
     TBG_ROWSN(4, 1) TBG_ROWSN(4, 2)
 #undef TBG_ROWSN
 #undef TBG_ROWS1
+#undef TBG_ODD
 #undef TBG_GO
     if (!done) {
         lpx_set_error("lpx_batched_tableau_solve: no kernel for m = %d, n - m = %d", m, k);

@@ -535,11 +535,14 @@ def test_batched_tableau_inequality_form_equals_materialised_problem(m, k):
         assert ri[i].basis.tolist() == rf[i].basis.tolist() and ri[i].optimum
 
 
-@pytest.mark.parametrize("m,n", [(8, 16), (13, 40), (32, 64), (37, 100), (64, 128), (60, 124)])
+@pytest.mark.parametrize("m,n", [(8, 16), (13, 40), (32, 64), (37, 100), (64, 128), (60, 124), (80, 170), (65, 130),
+                                 (64, 256), (128, 256), (100, 340), (200, 300), (2, 200), (129, 257)])
 def test_batched_dual_tableau_kernel_bit_identical_to_the_dual_tableau_oracle(m, n):
-    """lpx_batched_tableau_dual_solve: per LP the pivot log, x, cost, basis, iters and status of the oracle's dual tableau
-    loop, bit for bit; the revised-form dual kernel takes the same pivots."""
+    """lpx_batched_tableau_dual_solve (one wave per LP, a grid of waves beyond 64 x 64 slots): per LP the pivot log, x, cost,
+    basis, iters and status of the oracle's dual tableau loop, bit for bit; the revised-form dual kernel takes the same
+    pivots (shapes it holds)."""
     from linprog_amd.batched import BatchedDualSolver, BatchedDualTableauSolver
+    from linprog_amd.exceptions import LpxBackendError
     from oracle import oracle as O
 
     probs = [gen.gen_dual(m, n, 400 + s) for s in range(5)]
@@ -547,11 +550,16 @@ def test_batched_dual_tableau_kernel_bit_identical_to_the_dual_tableau_oracle(m,
     for maxiters in (100000, 9):
         tab = BatchedDualTableauSolver(*args, log_cap=2048)
         rt = tab.solve(maxiters)
-        rev = BatchedDualSolver(*args, log_cap=2048)
-        rev.solve(maxiters)
+        try:
+            rev = BatchedDualSolver(*args, log_cap=2048)
+            rev.solve(maxiters)
+        except (LpxBackendError, ValueError):
+            assert m > 64 or n > 256
+            rev = None
         for i, p in enumerate(probs):
             o = O.OracleTableau(*p, kind="dual", log_cap=2048).solve(maxiters)
-            assert tab.pivot_logs()[i].tolist() == o.log.tolist() == rev.pivot_logs()[i].tolist()
+            assert tab.pivot_logs()[i].tolist() == o.log.tolist()
+            assert rev is None or o.log.tolist() == rev.pivot_logs()[i].tolist()
             assert rt[i].iters == o.iters and rt[i].optimum is (True if o.status == O.OPTIMAL else None)
             assert np.array_equal(rt[i].x, o.x) and rt[i].cost == o.cost
             assert rt[i].basis.tolist() == o.basis.tolist()
@@ -585,7 +593,7 @@ def test_batched_tableau_kernel_on_degenerate_goldens():
             assert_close(res[i].cost, ref["cost"], "cost")
 
 
-@pytest.mark.parametrize("m,n", [(5, 12), (16, 32), (37, 100), (64, 128)])
+@pytest.mark.parametrize("m,n", [(5, 12), (16, 32), (37, 100), (64, 128), (80, 170), (64, 256), (130, 250)])
 def test_batched_tableau_kernel_from_a_general_starting_basis(m, n):
     """lpx_batched_tableau_solve_from: any primal feasible starting basis (here the basis after 9 oracle pivots; one LP of
     the batch starts from a permuted slack basis).  The float32 constructor state of the reference (primal_solvers.py:37-38,
