@@ -30,7 +30,7 @@ struct TabWs {
     // column, the ratio partials and the entering decision exist twice and alternate with the parity of the pivot
     double *d2[2];
     FusedPart fp[2];
-    double *next[2]; // {min rc, entering variable, its column slot, optimal?}
+    double *next[2]; // primal: {min rc, entering variable, its column slot, optimal?}; dual: the TD_* record
     int64_t *base;   // pivots at the start of the current lpx_tableau_iterate call
     double *pend;    // partitioned dual loop with lookahead: {leaving row, optimal?, min x_B} decided one pivot ahead
     int64_t bytes;
@@ -65,7 +65,7 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
         w.fp[q].dmax = (double *)tcarve(p, 8 * TF_MAXLA);
         w.fp[q].dbest = (double *)tcarve(p, 8 * TF_MAXLA);
         w.fp[q].bvar = (int64_t *)tcarve(p, 8 * TF_MAXLA);
-        w.next[q] = (double *)tcarve(p, 8 * 8);
+        w.next[q] = (double *)tcarve(p, 8 * 16);
     }
     w.base = (int64_t *)tcarve(p, 8 * 2);
     w.pend = (double *)tcarve(p, 8 * 4);
@@ -895,6 +895,335 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_syncback(lpx_tableau s, const i
         *(d2_t *)(s.T + t) = *(const d2_t *)(Talt + t);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The single-launch chain for the DUAL rules (dual_solvers.py:47-108): the same launch structure -- lookahead
+// workgroups, update workgroups, one bookkeeper, two buffers, records alternating with the parity of the pivot -- with
+// the dual's order of decisions.  While pivot t's update streams Tin -> Tout, every lookahead workgroup forms, from Tin,
+// the pending eta column and the old pivot row (K1's expressions, bit for bit what the update writes):
+//   1. the x_B column after the update -> leaving row r' = first x_B < 0, optimality test (whole column, redundantly);
+//   2. row r' and the reduced-cost row after the update -> theta_j = (-rc_j) / row_j over row_j < 0, first argmin by
+//      variable id -> entering j' (whole rows, redundantly), min(row) for the unboundedness test;
+//   3. its own 256 rows of column j' after the update -> the next entering column (dn), the pivot element d_r'.
+// Four dependent round trips (decision record -> x_B[r] -> row r' -> column j').  The decision record of a pivot:
+enum { TD_MIN = 0, TD_R, TD_OPT, TD_TH, TD_J, TD_K, TD_ROWMIN, TD_DR, TD_LEAVING, TD_LEN };
+// ---------------------------------------------------------------------------------------------------------
+struct DualFusedArgs {
+    lpx_tableau s;
+    const double *Tin;
+    double *Tout;
+    const double *dc; // entering column of this pivot, m + 1 entries (dc[m] = its reduced cost)
+    double *dn;
+    const double *nc; // decision record of this pivot (TD_*)
+    double *nn;
+    int64_t *base;
+    int64_t nla, nstrips, rpb;
+};
+// first batch of the loads whose addresses do not depend on this pivot's record
+struct TdLaPre {
+    double xi[TF_UN], dci[TF_UN]; // x_B column and pending entering column, rows tid + u * TF_THREADS
+    double rcm[TF_UN];            // reduced-cost row, columns tid + u * TF_THREADS
+    int64_t var[TF_UN];
+    double dcm, dc_own;           // dc[m]; dc of this thread's own row (column gather)
+};
+template <bool BOOT>
+__device__ __forceinline__ TdLaPre td_la_preload(const DualFusedArgs &a, int64_t q)
+{
+    const lpx_tableau &s = a.s;
+    const int64_t m = s.m, n = s.n, ld = s.ld;
+    TdLaPre p;
+#pragma unroll
+    for (int u = 0; u < TF_UN; ++u) {
+        const int64_t i = threadIdx.x + (int64_t)u * TF_THREADS;
+        p.xi[u] = (i < m) ? a.Tin[i * ld + n] : 0.0;
+        p.dci[u] = (!BOOT && i < m) ? a.dc[i] : 0.0;
+        p.rcm[u] = (i < n) ? a.Tin[m * ld + i] : 0.0;
+        p.var[u] = (i >= n) ? LPX_NOIDX : (s.slot_var ? s.slot_var[i] : s.col0 + i);
+    }
+    const int64_t own = q * TF_THREADS + threadIdx.x;
+    p.dcm = BOOT ? 0.0 : a.dc[m];
+    p.dc_own = (!BOOT && own <= m) ? a.dc[own] : 0.0;
+    return p;
+}
+template <bool BOOT>
+__device__ __forceinline__ void td_lookahead(const DualFusedArgs &a, int64_t q, const TdLaPre &pre, int64_t r, double dr,
+                                             int64_t j, int64_t k, int64_t leaving, bool f32)
+{
+    __shared__ BlockRed red;
+    __shared__ int64_t sslot;
+    const lpx_tableau &s = a.s;
+    const int64_t m = s.m, n = s.n, ld = s.ld;
+    const bool cond = s.slot_var != nullptr;
+    const int tid = threadIdx.x;
+    const double *Tin = a.Tin;
+    // ---- 1. the x_B column as the update leaves it (primal_solvers.py:251-253), leaving row (dual_solvers.py:47-54)
+    const double xr = BOOT ? 0.0 : Tin[r * ld + n];
+    double mn = LPX_INF;
+    int64_t first = LPX_NOIDX;
+    for (int64_t i0 = tid; i0 < m; i0 += TF_THREADS * TF_UN) {
+        double xi[TF_UN], dci[TF_UN];
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = i0 + (int64_t)u * TF_THREADS;
+            if (i0 == tid) {
+                xi[u] = pre.xi[u];
+                dci[u] = pre.dci[u];
+            } else {
+                xi[u] = (i < m) ? Tin[i * ld + n] : 0.0;
+                dci[u] = (!BOOT && i < m) ? a.dc[i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = i0 + (int64_t)u * TF_THREADS;
+            if (i >= m) continue;
+            double xb = xi[u];
+            if (!BOOT) {
+                const double ei = (i == r) ? 1.0 / dr : (-dci[u]) / dr;
+                xb = (i == r) ? ei * xr : fma(ei, xr, xi[u]);
+            }
+            mn = fmin(mn, xb);
+            if (xb < 0.0 && i < first) first = i;
+        }
+    }
+    mn = block_min(mn, red);
+    const int64_t r2 = block_imin(first, red);
+    const bool opt = lpx_is_optimal_min(mn);
+    if (opt) {
+        if (q == 0 && tid == 0) {
+            a.nn[TD_MIN] = mn;
+            a.nn[TD_OPT] = 1.0;
+            a.nn[TD_R] = 0.0;
+            a.nn[TD_ROWMIN] = -1.0;
+        }
+        return;
+    }
+    // ---- 2. row r2 and the reduced-cost row as the update leaves them; ratio test over the columns (:61-80)
+    const double em = BOOT ? 0.0 : (-pre.dcm) / dr;
+    const double er2 = BOOT ? 0.0 : ((r2 == r) ? 1.0 / dr : (-a.dc[r2]) / dr);
+    const int64_t bs2 = (!BOOT && r2 == r) ? j : s.basis[r2]; // the basic variable of row r2 as this pivot leaves it
+    VI best{LPX_INF, LPX_NOIDX};
+    int64_t bslot = -1;
+    double rowmin = LPX_INF;
+    for (int64_t c0 = tid; c0 < n; c0 += TF_THREADS * TF_UN) {
+        double pr[TF_UN], rcm[TF_UN], rw[TF_UN];
+        int64_t var[TF_UN];
+        int32_t vst[TF_UN];
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t c = c0 + (int64_t)u * TF_THREADS;
+            const bool ok = c < n;
+            pr[u] = (ok && !BOOT) ? Tin[r * ld + c] : 0.0;
+            rw[u] = ok ? Tin[r2 * ld + c] : 0.0;
+            vst[u] = (ok && !cond) ? s.var_state[c] : LPX_VS_LOWER;
+            if (c0 == tid) {
+                rcm[u] = pre.rcm[u];
+                var[u] = pre.var[u];
+            } else {
+                rcm[u] = ok ? Tin[m * ld + c] : 0.0;
+                var[u] = !ok ? LPX_NOIDX : (cond ? s.slot_var[c] : s.col0 + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t c = c0 + (int64_t)u * TF_THREADS;
+            if (c >= n) continue;
+            double row = rw[u], rc = rcm[u];
+            int64_t v = var[u];
+            bool basic = !cond && vst[u] == LPX_VS_BASIC;
+            if (!BOOT) {
+                if (c == k) { // the column the update rewrites as a whole: eta column (condensed) / unit vector (full)
+                    row = cond ? er2 : ((r2 == r) ? 1.0 : 0.0);
+                    rc = cond ? em : 0.0;
+                    v = cond ? leaving : v;
+                    basic = !cond;
+                } else {
+                    row = (r2 == r) ? er2 * pr[u] : fma(er2, pr[u], rw[u]);
+                    rc = fma(em, pr[u], rcm[u]);
+                    if (!cond && v == leaving) basic = false; // leaves the basis with this pivot
+                }
+            }
+            if (basic) row = 0.0; // dual_solvers.py:38-39
+            const double th = lpx_dsd(rc, row, f32);
+            if (vi_less(th, v, best.v, best.i)) { best.v = th; best.i = v; bslot = c; }
+            rowmin = fmin(rowmin, row);
+        }
+    }
+    const VI win = block_argmin(best, red);
+    rowmin = block_min(rowmin, red);
+    if (best.i == win.i && best.v == win.v && bslot >= 0) sslot = bslot; // variable ids are distinct: one thread
+    __syncthreads();
+    const int64_t kp = sslot;
+    if (q == 0 && tid == 0) {
+        a.nn[TD_MIN] = mn;
+        a.nn[TD_R] = (double)r2;
+        a.nn[TD_OPT] = 0.0;
+        a.nn[TD_TH] = win.v;
+        a.nn[TD_J] = (double)win.i; // exact: ids < 2^53
+        a.nn[TD_K] = (double)kp;
+        a.nn[TD_ROWMIN] = rowmin;
+        a.nn[TD_LEAVING] = (double)bs2;
+    }
+    if (rowmin >= 0.0) return; // dual unbounded (:41-44, :56-59): the next launch stops before it needs a column
+    // ---- 3. this workgroup's rows of the next entering column as the update leaves it
+    const int64_t i = q * TF_THREADS + tid;
+    if (i <= m) {
+        double dv;
+        if (BOOT) {
+            dv = Tin[i * ld + kp];
+        } else {
+            const double ei = (i == r) ? 1.0 / dr : (-pre.dc_own) / dr; // primal_solvers.py:236-244
+            if (kp == k) dv = cond ? ei : ((i == r) ? 1.0 : 0.0);
+            else {
+                const double prk = Tin[r * ld + kp];
+                dv = (i == r) ? ei * prk : fma(ei, prk, Tin[i * ld + kp]);
+            }
+        }
+        a.dn[i] = dv;
+        if (i == r2) a.nn[TD_DR] = dv;
+    }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_td_boot(DualFusedArgs a)
+{
+    lpx_ctrl *ctrl = a.s.ctrl;
+    const TdLaPre pre = td_la_preload<true>(a, blockIdx.x);
+    const int32_t status = ctrl->status, f32 = ctrl->f32_phase;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.base = ctrl->pivots; // also when the loop has ended: k_t_syncback reads it
+    if (status != LPX_RUNNING) return;
+    td_lookahead<true>(a, blockIdx.x, pre, 0, 1.0, 0, -1, 0, f32 != 0);
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_td_fused(DualFusedArgs a)
+{
+    const lpx_tableau &s = a.s;
+    lpx_ctrl *ctrl = s.ctrl;
+    const int64_t m = s.m, ld = s.ld;
+    const bool is_la = (int64_t)blockIdx.x < a.nla;
+    const bool is_book = blockIdx.x == gridDim.x - 1; // the last workgroup keeps the books
+    // ---- round trip 1: everything whose address does not depend on this pivot's decisions
+    const int32_t status = ctrl->status;
+    const int64_t counter0 = ctrl->counter, pivots0 = ctrl->pivots; // used by the bookkeeper only
+    double rec[TD_LEN];
+#pragma unroll
+    for (int u = 0; u < TD_LEN; ++u) rec[u] = a.nc[u];
+    TdLaPre pre;
+    d2_t x[TF_UN];
+    double di[TF_UN];
+    int64_t row0 = 0, row1 = 0, col = 0;
+    bool live = false;
+    if (is_la) {
+        pre = td_la_preload<false>(a, blockIdx.x);
+    } else if (!is_book) {
+        const uint32_t w = blockIdx.x - (uint32_t)a.nla; // 32-bit division: the grid has < 2^31 workgroups
+        const int64_t band = w / (uint32_t)a.nstrips, sx = w - (uint32_t)band * (uint32_t)a.nstrips;
+        row0 = band * a.rpb;
+        row1 = (row0 + a.rpb < m + 1) ? row0 + a.rpb : m + 1;
+        col = (sx * TF_THREADS + threadIdx.x) * 2;
+        live = col <= s.n; // columns 0 .. n (column n is x_B); ld is even, so the pair stays inside the row
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = row0 + u;
+            if (live && i < row1) {
+                x[u] = *(const d2_t *)(a.Tin + i * ld + col);
+                di[u] = a.dc[i];
+            }
+        }
+    }
+    if (status != LPX_RUNNING) return;
+    const bool lead = is_book && threadIdx.x == 0;
+    const double mn = rec[TD_MIN];
+    if (rec[TD_OPT] != 0.0) { // dual_solvers.py:52-54
+        if (lead) {
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            ctrl->status = LPX_OPTIMAL;
+        }
+        return;
+    }
+    const int64_t r = (int64_t)rec[TD_R];
+    if (rec[TD_ROWMIN] >= 0.0) { // :41-44, :56-59
+        if (lead) {
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            ctrl->leave_r = r;
+            ctrl->aux_val = rec[TD_ROWMIN];
+            ctrl->status = LPX_DUAL_UNBOUNDED;
+        }
+        return;
+    }
+    const int64_t j = (int64_t)rec[TD_J], k = (int64_t)rec[TD_K], leaving = (int64_t)rec[TD_LEAVING];
+    const double dr = rec[TD_DR];
+    if (is_book) {
+        if (threadIdx.x == 0) { // k_td_ratio's and td_finish's bookkeeping; nothing below is read by this launch
+            ctrl->counter = counter0 + 1;
+            ctrl->price_val = mn;
+            s.basis[r] = j;
+            if (s.slot_var) {
+                s.slot_var[k] = leaving;
+                s.var_slot[leaving] = k;
+                s.var_slot[j] = -1;
+            } else {
+                const int64_t ll = leaving - s.col0;
+                if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
+                s.var_state[k] = LPX_VS_BASIC;
+            }
+            ctrl->enter_slot = k;
+            if (s.log && pivots0 < s.log_cap) {
+                s.log[3 * pivots0 + 0] = r;
+                s.log[3 * pivots0 + 1] = j;
+                s.log[3 * pivots0 + 2] = leaving;
+            }
+            ctrl->pivots = pivots0 + 1;
+            ctrl->leave_r = r;
+            ctrl->enter_j = j;
+            ctrl->leave_var = leaving;
+            ctrl->ratio_val = rec[TD_TH];
+            ctrl->aux_val = rec[TD_ROWMIN];
+            ctrl->flip = 0;
+            ctrl->f32_phase = 0;
+        }
+        return;
+    }
+    if (is_la) {
+        td_lookahead<false>(a, blockIdx.x, pre, r, dr, j, k, leaving, false);
+        return;
+    }
+    // ---- update workgroup: rows [row0, row1) x one strip of 2 * TF_THREADS columns, Tin -> Tout (as k_t_fused)
+    if (!live) return;
+    const bool cond = s.slot_var != nullptr;
+    const d2_t pr = *(const d2_t *)(a.Tin + r * ld + col); // the old pivot row
+    const bool fix0 = col == k, fix1 = col + 1 == k;
+    for (int64_t i0 = row0; i0 < row1; i0 += TF_UN) { // TF_UN rows in flight
+        if (i0 != row0) {
+#pragma unroll
+            for (int u = 0; u < TF_UN; ++u) {
+                const int64_t i = i0 + u;
+                if (i < row1) {
+                    x[u] = *(const d2_t *)(a.Tin + i * ld + col);
+                    di[u] = a.dc[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_UN; ++u) {
+            const int64_t i = i0 + u;
+            if (i >= row1) break;
+            const bool isr = i == r;
+            const double ei = isr ? 1.0 / dr : (-di[u]) / dr; // :236-244, row m: eliminates rc_j
+            if (isr) {
+                x[u][0] = ei * pr[0];
+                x[u][1] = ei * pr[1];
+            } else {
+                x[u][0] = fma(ei, pr[0], x[u][0]);
+                x[u][1] = fma(ei, pr[1], x[u][1]);
+            }
+            if (fix0) x[u][0] = cond ? ei : (isr ? 1.0 : 0.0);
+            if (fix1) x[u][1] = cond ? ei : (isr ? 1.0 : 0.0);
+            *(d2_t *)(a.Tout + i * ld + col) = x[u];
+        }
+    }
+}
+
 static inline bool t_use_fused(const lpx_tableau *s)
 {
     if (s->T_alt == nullptr || lpx_env_int("LPX_TABLEAU_FUSED", 1) == 0) return false;
@@ -1436,6 +1765,62 @@ static void td_launch_select(const lpx_tableau *s, const TabWs &w, const Rank1Pl
     hipLaunchKernelGGL(k_td_ratio, dim3(p.grid.x), dim3(LPX_BLOCK), 0, st, *s, w.ratio, nrow, w.price, strip);
 }
 
+static int tableau_dual_iterate_fused(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st)
+{
+    LPX_REQUIRE(lpx_aligned16(s->T_alt), "T_alt must be 16-byte aligned");
+    DualFusedArgs a{};
+    a.s = *s;
+    a.base = w.base;
+    a.nla = lpx_cdiv(s->m + 1, TF_THREADS);
+    a.nstrips = lpx_cdiv(s->n + 1, 2 * TF_THREADS);
+    int64_t rpb = lpx_env_int("LPX_FUSED_ROWS", 0); // as tableau_iterate_fused
+    if (rpb <= 0) {
+        rpb = 1;
+        while (rpb < 8 && a.nstrips * lpx_cdiv(s->m + 1, 2 * rpb) >= 240) rpb *= 2;
+    }
+    a.rpb = rpb;
+    const int64_t nupd = a.nstrips * lpx_cdiv(s->m + 1, rpb);
+    LPX_REQUIRE(a.nla + nupd + 1 < ((int64_t)1 << 31), "grid too large");
+    auto args_for = [&](int par) {
+        DualFusedArgs b = a;
+        b.Tin = par ? s->T_alt : s->T;
+        b.Tout = par ? s->T : s->T_alt;
+        b.dc = w.d2[par]; b.dn = w.d2[par ^ 1];
+        b.nc = w.next[par]; b.nn = w.next[par ^ 1];
+        return b;
+    };
+    { // bootstrap: leaving row, ratio test and entering column of the state in T -> the records of parity 0
+        DualFusedArgs b = args_for(1);
+        b.Tin = s->T;
+        b.Tout = nullptr;
+        hipLaunchKernelGGL(k_td_boot, dim3((unsigned)a.nla), dim3(TF_THREADS), 0, st, b);
+    }
+    int64_t it = 0;
+    auto one = [&](hipStream_t q) {
+        const DualFusedArgs b = args_for((int)(it & 1));
+        lpx_k1_begin(q);
+        hipLaunchKernelGGL(k_td_fused, dim3((unsigned)(a.nla + nupd + 1)), dim3(TF_THREADS), 0, q, b);
+        lpx_k1_end(q);
+        it += 1;
+    };
+    struct {
+        lpx_tableau s;
+        int64_t rpb;
+        int what;
+    } key;
+    memset(&key, 0, sizeof key);
+    key.s = *s; key.rpb = rpb; key.what = 4;
+    const int rc = lpx_run_iterations(&key, sizeof key, iters, st, one);
+    const int64_t count = (s->m + 1) * s->ld;
+    int64_t nb = lpx_cdiv(count / 2, LPX_BLOCK);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_t_syncback, dim3((unsigned)nb), dim3(LPX_BLOCK), 0, st, *s, (const int64_t *)w.base,
+                       (const double *)s->T_alt, count);
+    if (rc) return rc;
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
     int rc = check_tableau(s);
@@ -1446,6 +1831,7 @@ extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, voi
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
     if (iters <= 0) return LPX_OK;
+    if (t_use_fused(s)) return tableau_dual_iterate_fused(s, w, iters, st);
     const lpx_tableau sv = *s;
     auto one = [&](hipStream_t q) {
         td_launch_select(&sv, w, plan, q);

@@ -140,11 +140,11 @@ class TableauEngine:
         s.workspace, s.workspace_bytes = self.workspace.data_ptr(), ws
         s.slot_var = None if slot_var is None else slot_var.data_ptr()
         s.var_slot = None if var_slot is None else var_slot.data_ptr()
-        # launch-bound sizes (unpartitioned primal loop): a second buffer lets liblpx run one launch per pivot, the
+        # launch-bound sizes (unpartitioned loops, primal and dual): a second buffer lets liblpx run one launch per pivot, the
         # tableau ping-ponging between the two (lpx.h, lpx_tableau.T_alt); beyond FUSED_MAX_BYTES the update is
         # HBM-bound, the three-kernel in-place chain costs nothing and the memory is better left alone
         self.T_alt = None
-        if group is None and not self.dual and T.numel() * 8 <= self.FUSED_MAX_BYTES:
+        if group is None and T.numel() * 8 <= self.FUSED_MAX_BYTES:
             self.T_alt = torch.zeros_like(T)
         s.T_alt = None if self.T_alt is None else self.T_alt.data_ptr()
         _lib.check(self.lib.lpx_ctrl_init(s.ctrl, int(f32_phase), stream_ptr()))

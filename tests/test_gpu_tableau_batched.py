@@ -249,15 +249,19 @@ def test_tableau_dantzig_opt_in_matches_oracle(m, n, seed):
 DUAL_CASES = [c for c in load("random.json") + load("textbook.json") + load("random_xlarge.json") if c["solver"].startswith("Dual")]
 
 
+@pytest.mark.parametrize("chain", ["one-launch", "four-launch"])
 @pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
 @pytest.mark.parametrize("cs", DUAL_CASES, ids=case_id)
-def test_dual_tableau_matches_reference(cs, condensed):
+def test_dual_tableau_matches_reference(cs, condensed, chain, monkeypatch):
     """DualTableauSimplexSolver takes DualNaive/DualRevisedSimplexSolver's pivots (goldens), raises where they raise,
-    and is bit-identical to the oracle's dual tableau loop."""
+    and is bit-identical to the oracle's dual tableau loop -- through both launch chains: one launch per pivot on two
+    alternating buffers (k_td_fused, default at these sizes) and the in-place row -> ratio -> prepare -> update chain."""
     from linprog_amd import exceptions
     from linprog_amd.tableau import DualTableauSimplexSolver
     from oracle import oracle as O
 
+    if chain == "four-launch":
+        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
     ref = cs["ref"]
     c, A, b, basis = problem_of(cs)
     if ref["exception"] == "BasisIsDualInfeasibleError":
@@ -289,6 +293,49 @@ def test_dual_tableau_matches_reference(cs, condensed):
         # same layout as the oracle's (or an exact identity start, where the layouts cannot differ): bit-identical x
         assert np.array_equal(res.x, ro.x)  # the cost is a tree dot on the device, sequential in the oracle
         assert abs(res.cost - ro.cost) <= 1e-13 * max(1.0, abs(ro.cost))
+
+
+@pytest.mark.parametrize("rows", ["0", "1", "4"])
+@pytest.mark.parametrize("m,n,condensed", [(300, 700, True), (300, 700, False), (530, 1061, True), (64, 1200, True),
+                                           (700, 760, True)])
+def test_dual_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, monkeypatch):
+    """The dual single-launch chain with several lookahead workgroups, several column strips and every update tile
+    height, in calls of odd and even length (ping-pong parity, hipGraph replays): pivot log, tableau, basis and column
+    maps bit-identical to the oracle's dual loop on the same layout; then on to the optimum, and a further solve() there
+    moves nothing."""
+    from linprog_amd.tableau import DualTableauSimplexSolver
+    from oracle import oracle as O
+
+    monkeypatch.setenv("LPX_FUSED_ROWS", rows)
+    c, A, b, basis = gen.gen_dual(m, n, 5)
+    s = logged(DualTableauSimplexSolver, 4096)(c, A, b, basis, condensed=condensed)
+    assert s._engine.T_alt is not None
+    o = O.OracleTableau(c, A, b, basis, kind="dual", log_cap=4096)  # every column (the oracle's dual layout)
+    done = 0
+    for k in (1, 2, 5, 64, 33):
+        res = s.solve(k)
+        r = o.solve(k)
+        done += k
+        assert s.pivot_log().tolist() == o.log[:done].tolist()
+        eng = s._engine
+        T = eng.T.cpu().numpy()
+        if condensed:  # slot q carries variable slot_var[q]; the slots and the basis partition the variables
+            slot_var, var_slot = eng.slot_var.cpu().numpy(), eng.var_slot.cpu().numpy()
+            assert sorted(slot_var.tolist() + res.basis.tolist()) == list(range(n))
+            assert np.array_equal(var_slot[slot_var], np.arange(eng.n)) and np.all(var_slot[res.basis] == -1)
+            assert np.array_equal(T[:, :eng.n], o.T[:, slot_var]) and np.array_equal(T[:, eng.n], o.T[:, n])
+        else:
+            assert np.array_equal(T[:, :n + 1], o.T[:, :n + 1])
+        assert res.basis.tolist() == r.basis.tolist() and res.iters == r.iters and np.array_equal(res.x, r.x)
+        assert_close(res.cost, r.cost, "cost")  # dot(c, x): the device sums it as a tree, the oracle in index order
+    res = s.solve(100000)
+    r = o.solve(100000)
+    assert res.optimum is True and r.status == O.OPTIMAL and res.iters == r.iters
+    gl = s.pivot_log().tolist()
+    assert len(gl) == done + res.iters - 1 and gl == o.log[:len(gl)].tolist() and np.array_equal(res.x, r.x)
+    T0 = s._engine.T.clone()
+    again = s.solve(100)
+    assert again.optimum is True and again.iters == 1 and bool((s._engine.T == T0).all())
 
 
 @pytest.mark.parametrize("m,n,seed", [(300, 700, 5), (1000, 2000, 6)])
