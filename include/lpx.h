@@ -131,9 +131,10 @@ typedef struct lpx_tableau {
     int64_t *slot_var;
     int64_t *var_slot;
     /* Optional second buffer of the size of T ((m+1) x ld doubles, 16-byte aligned), or NULL.  With it, lpx_tableau_iterate
-     * and lpx_tableau_dual_iterate run tableaus of up to 16384 rows and 32767 columns as ONE launch per pivot: the tableau ping-pongs between T and
-     * T_alt while lookahead workgroups of the same launch prepare the next pivot's decisions (lpx_tableau.hip).  The state
-     * is in T again whenever a call returns; T_alt's contents are scratch between calls.  Same arithmetic, same bits. */
+     * and lpx_tableau_dual_iterate run tableaus of up to 16384 rows and 32767 columns as ONE launch per pivot: the
+     * tableau ping-pongs between T and T_alt while lookahead workgroups of the same launch prepare the next pivot's
+     * decisions (lpx_tableau.hip).  The state is in T again whenever a call returns; T_alt's contents are scratch
+     * between calls.  Same arithmetic, same bits. */
     double *T_alt;
 } lpx_tableau;
 
