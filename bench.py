@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "dual10k", "config5"])
+    ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "dual10k", "dual1k", "config5"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--m", type=int, default=None, help="tableau workloads: rows (default: the config's)")
@@ -115,7 +115,7 @@ def main():
         return bench_revised(args)
     if args.workload == "config5":
         return bench_config5(args)
-    if args.workload == "dual10k":
+    if args.workload in ("dual10k", "dual1k"):
         return bench_dual(args)
     if args.workload == "tableau1k":
         return finish(bench_tableau(args, rank, world, group, args.m or 1000, args.n or 2000, args.steps, args.warmup))
@@ -357,8 +357,9 @@ def bench_revised(args):
 
 
 def bench_dual(args):
-    """The dual simplex (dual_solvers.py:82-108) at 10000 x 20000 from gen_dual's dual-feasible slack basis, in both forms:
-    the carried (condensed) tableau and the revised form.  Value = the tableau form's pivots/s."""
+    """The dual simplex (dual_solvers.py:82-108) at 10000 x 20000 (dual10k) or 1000 x 2000 (dual1k: the launch-bound size, one
+    launch per pivot) from gen_dual's dual-feasible slack basis, in both forms: the carried (condensed) tableau and the
+    revised form.  Value = the tableau form's pivots/s."""
     import ctypes as C
 
     import torch
@@ -368,7 +369,7 @@ def bench_dual(args):
     from linprog_amd.tableau import DualTableauSimplexSolver
     from oracle import oracle as O
 
-    m, n = 10000, 20000
+    m, n = (args.m or 1000, args.n or 2000) if args.workload == "dual1k" else (args.m or 10000, args.n or 20000)
     K, W = args.steps, args.warmup
     c, A, b, basis = problems.gen_dual(m, n, args.seed)
     lib = _lib.load()
@@ -399,6 +400,7 @@ def bench_dual(args):
     dt_t, k1_t = run(tab, lambda eng, k: eng.enqueue(k))
     log_t = tab.pivot_log()
     ncarry = tab._engine.n
+    one_launch = tab._engine.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
     del tab
     torch.cuda.empty_cache()
     Rev = type("BenchDualRevised", (DualRevisedSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
@@ -408,7 +410,7 @@ def bench_dual(args):
     same = min(len(log_t), len(log_r))
     if log_t[:same].tolist() != log_r[:same].tolist():
         sys.exit("bench invalid: the tableau and the revised form took different dual pivots")
-    kc = args.cpu_pivots if args.cpu_pivots is not None else 6
+    kc = args.cpu_pivots if args.cpu_pivots is not None else (6 if m >= 5000 else min(K, 300))
     cpu = None
     if kc > 0:
         o = O.OracleRevised(c, A, b, basis, kind="dual", log_cap=kc + 1)
@@ -427,8 +429,10 @@ def bench_dual(args):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"gen_dual(m={m}, n={n}, seed={args.seed}) DualTableauSimplexSolver loop (condensed tableau, "
                                   f"{m + 1} x {ncarry + 1})", "m": m, "n": n,
+                      "launches_per_pivot": 1 if one_launch else 4,
                       "revised_form_pivots_per_s": K / dt_r, "revised_form_k1_ms": k1_r * 1e3},
-           "roofline": {"bound": "hbm", "kernel": "k_rank1<tableau>", "achieved": bytes_t / k1_t / 1e9, "peak": HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "kernel": "k_td_fused (update + next pivot's leaving row / ratio test / column, two "
+                                                  "buffers)" if one_launch else "k_rank1<tableau>", "achieved": bytes_t / k1_t / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": bytes_t / k1_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "bytes_per_launch": bytes_t, "avg_launch_ms": k1_t * 1e3},
            "cpu_baseline": cpu}
