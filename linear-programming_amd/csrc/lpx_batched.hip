@@ -886,6 +886,7 @@ struct BlockArgs {
     double *pd_y;                // m, dual vector, in/out
     const double *pd_c64;        // n_orig float64 costs of the unrestricted problem
     int64_t pd_n_orig, pd_maxiters1;
+    int a_in_lds;                // A (m x n float32) is copied into LDS behind the solver state (the launch made room)
 };
 struct BlockLds {
     double *Binv, *xB, *y, *d, *e, *rowr, *w, *rc, *row, *lb, *ub, *bu, *yd, *v;
@@ -926,6 +927,16 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
     return L;
 }
 #define LPX_BLOCK_LDS_MAX (158 * 1024)
+// A beside the state in LDS when both fit: a lone workgroup has nothing to hide an L2 round trip behind, and every chain
+// over A (reduced costs, direction, the bounded solver's b - A_lb lb - A_ub ub) waits for one per 32 steps.  Odd row
+// stride: conflict-free both down a column (lane = column) and along a row (lane = row).
+__host__ __device__ static inline int64_t block_lds_A_ld(int64_t n) { return n | 1; }
+__host__ __device__ static inline int64_t block_lds_A_bytes(int64_t m, int64_t n) { return 4 * m * block_lds_A_ld(n); }
+static inline bool block_A_fits(int64_t state_bytes, int64_t m, int64_t n)
+{
+    static const bool on = [] { const char *e = getenv("LPX_SMALL_A_LDS"); return !(e && e[0] == '0'); }();
+    return on && state_bytes + block_lds_A_bytes(m, n) <= LPX_BLOCK_LDS_MAX;
+}
 
 // PD: PrimalDualAlgorithm.solve (special_solvers.py:402-447) around the primal loop -- per outer iteration the admissible
 // set J = isclose(y A, c) (:405-406), a FRESH restricted primal on [A_J | I] from the artificial basis (:408-425, the
@@ -942,10 +953,21 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
     const int m = (int)s.m, n = (int)s.n, t = threadIdx.x;
-    const int64_t ldA = s.ldA;
+    int64_t ldA = s.ldA;
     const BlockLds L = block_lds(m, n, PD ? LPX_KIND_PD : KIND, smem);
     const int ldb = (int)L.ldb;
-    const float *A = s.A;
+    const float *A = s.A, *At = s.At;
+    if (a.a_in_lds) {
+        float *Al = (float *)(smem + L.bytes);
+        const int ldl = (int)block_lds_A_ld(n);
+        for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
+            const int i = idx / n, k = idx - i * n;
+            Al[i * ldl + k] = s.A[(int64_t)i * s.ldA + k];
+        }
+        A = Al;
+        ldA = ldl;
+        At = nullptr; // a row of the LDS copy is read as it lies
+    }
     const int n_orig = PD ? (int)a.pd_n_orig : 0;
     int64_t outer = 0;
     int pd_status = LPX_RUNNING;
@@ -993,7 +1015,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         __syncthreads();
         if (t < m) {
             double accl, accu;
-            if (s.At != nullptr) block_dot2_g<double, 32>(L.rc, L.bu, s.At + t, s.ldAt, n, accl, accu);
+            if (At != nullptr) block_dot2_g<double, 32>(L.rc, L.bu, At + t, s.ldAt, n, accl, accu);
             else block_dot2_g<double, 32>(L.rc, L.bu, A + (int64_t)t * ldA, (int64_t)1, n, accl, accu);
             L.w[t] = ((double)s.b[t] - accl) - accu;
         }
@@ -1303,15 +1325,18 @@ extern "C" int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind)
     return block_lds(m, n, kind, nullptr).bytes;
 }
 
-static int block_launch(const BlockArgs &a, int64_t batch, int64_t m, int64_t n, int kind, hipStream_t st)
+static int block_launch(const BlockArgs &a0, int64_t batch, int64_t m, int64_t n, int kind, hipStream_t st)
 {
     LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "kind must be primal, dual or bounded");
-    const int64_t bytes = block_lds(m, n, kind, nullptr).bytes;
+    int64_t bytes = block_lds(m, n, kind, nullptr).bytes;
     if (bytes > LPX_BLOCK_LDS_MAX || m > 4096 || n > 65536) {
         lpx_set_error("lpx_revised_solve_small: the state of a %lld x %lld LP needs %lld B of LDS, one CU has %d", (long long)m,
                       (long long)n, (long long)bytes, LPX_BLOCK_LDS_MAX);
         return LPX_E_SIZE;
     }
+    BlockArgs a = a0;
+    a.a_in_lds = block_A_fits(bytes, m, n) ? 1 : 0;
+    if (a.a_in_lds) bytes += block_lds_A_bytes(m, n);
 #define LPX_BLOCK_GO(K)                                                                                                      \
     {                                                                                                                        \
         LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); \
@@ -1344,7 +1369,7 @@ extern "C" int lpx_pd_solve_small(const lpx_revised *s, double *y, const double 
     LPX_REQUIRE(s != nullptr && s->m > 0 && n_orig > 0 && s->n == n_orig + s->m, "the state must be the restricted primal [A | I]");
     LPX_REQUIRE(s->A && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
     LPX_REQUIRE(y && c64 && x && cost && maxiters1 >= 0 && maxiters2 >= 0, "bad arguments");
-    const int64_t bytes = block_lds(s->m, s->n, LPX_KIND_PD, nullptr).bytes;
+    int64_t bytes = block_lds(s->m, s->n, LPX_KIND_PD, nullptr).bytes;
     if (bytes > LPX_BLOCK_LDS_MAX) {
         lpx_set_error("lpx_pd_solve_small: the state of a %lld x %lld LP needs %lld B of LDS, one CU has %d", (long long)s->m,
                       (long long)n_orig, (long long)bytes, LPX_BLOCK_LDS_MAX);
@@ -1360,6 +1385,8 @@ extern "C" int lpx_pd_solve_small(const lpx_revised *s, double *y, const double 
     a.pd_c64 = c64;
     a.pd_n_orig = n_orig;
     a.pd_maxiters1 = maxiters1;
+    a.a_in_lds = block_A_fits(bytes, s->m, s->n) ? 1 : 0;
+    if (a.a_in_lds) bytes += block_lds_A_bytes(s->m, s->n);
     LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<LPX_KIND_PRIMAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((k_block_solve<LPX_KIND_PRIMAL, true>), dim3(1), dim3(LPX_BLOCK), (size_t)bytes, (hipStream_t)stream, a);
     LPX_LAUNCH_CHECK();
