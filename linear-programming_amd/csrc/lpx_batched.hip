@@ -142,6 +142,27 @@ __device__ __forceinline__ void batch_argmin_max(double &v, int &idx, double &w,
     __syncthreads();
 }
 
+// The same for the primal ratio test, where lane t holds row t (idx == threadIdx.x on the lanes that have a row, rows
+// ascend with the lane): only the value goes through DPP (2 dwords instead of 6), the first lane at the wave's minimum is
+// the first argmin (np.argmin).  Lanes without a row pass v = +inf.
+__device__ __forceinline__ void batch_row_argmin_max(double &v, int &idx, double &w, BatchRed &red)
+{
+    const double mn = wave_min(v);
+    w = wave_max(w);
+    const unsigned long long who = __ballot(v == mn);
+    const int wv = threadIdx.x >> 6;
+    const int first = who ? (wv << 6) + __ffsll((long long)who) - 1 : 0x7FFFFFFF; // empty only with NaNs
+    if ((threadIdx.x & 63) == 0) { red.v[wv] = mn; red.i[wv] = first; red.w[wv] = w; }
+    __syncthreads();
+    v = red.v[0]; idx = red.i[0]; w = red.w[0];
+#pragma unroll
+    for (int k = 1; k < LPX_WAVES; ++k) {
+        if (red.v[k] < v) { v = red.v[k]; idx = red.i[k]; } // strict: the earlier wave (lower rows) keeps ties
+        w = fmax(w, red.w[k]);
+    }
+    __syncthreads();
+}
+
 // Sequential dot product acc = fma(a_k, b_k, acc), k ascending (the oracle's order), with the LDS loads of 8
 // steps issued ahead of the 8 dependent fmas so that LDS latency overlaps the fma chain.
 template <typename AccT, typename TA, typename TB>
@@ -186,6 +207,41 @@ __device__ __forceinline__ AccT block_dot_g(const TA *pa, int sa, const TB *pb, 
         for (int u = 0; u < DEPTH; ++u)
             if (k + u < len) acc = fma((AccT)pa[(k + u) * sa], (AccT)y[u], acc);
     }
+    return acc;
+}
+
+// The same sequential dot product when operand a is CONTIGUOUS and 16-byte aligned in LDS: a is read as 16-byte vectors
+// (4 floats / 2 doubles per LDS instruction), 16 steps of loads ahead of their 16 dependent fmas.  The chains of the
+// one-workgroup kernel are bound by LDS instruction issue (~13 cycles each), not by the fma chain.  Same order of
+// operations, same bits.  (Issuing block b+1's loads before block b's fmas, as staged_blocks does, gained 5 % on the chain
+// over B^-1 and lost 25 % on the one over A.)
+template <typename TA> struct ChainVec;
+template <> struct ChainVec<float> {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    static constexpr int W = 4;
+};
+template <> struct ChainVec<double> {
+    typedef d2_t vec;
+    static constexpr int W = 2;
+};
+template <typename AccT, typename TA, typename TB>
+__device__ __forceinline__ AccT chain_dot_va(const TA *pa, const TB *pb, int64_t sb, int len)
+{
+    typedef typename ChainVec<TA>::vec vec;
+    constexpr int W = ChainVec<TA>::W, NV = 16 / W;
+    AccT acc = (AccT)0;
+    int k = 0;
+    for (; k + 16 <= len; k += 16) {
+        vec x[NV];
+        TB y[16];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) x[u] = *(const vec *)(pa + k + W * u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) y[u] = pb[(int64_t)(k + u) * sb];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma((AccT)x[u / W][u % W], (AccT)y[u], acc);
+    }
+    for (; k < len; ++k) acc = fma((AccT)pa[k], (AccT)pb[(int64_t)k * sb], acc);
     return acc;
 }
 
@@ -943,6 +999,16 @@ static inline bool block_A_fits(int64_t state_bytes, int64_t m, int64_t n)
 // reference's cold restart, float32 first iteration included), then while its cost is positive the restricted dual
 // y_rp = c_B B^-1, the unboundedness test (:435-436), theta (:438-443) and y += theta y_rp (:444).  One launch for the
 // whole algorithm instead of ~20 launches and two host round trips per outer iteration.
+// -DLPX_BLOCK_STAMPS: diagnostic build, thread 0 prints where the cycles of a solve went (never shipped)
+#ifdef LPX_BLOCK_STAMPS
+#define BS_DECL unsigned long long bs_last = clock64(), bs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BS(k) { const unsigned long long bs_now = clock64(); bs_acc[k] += bs_now - bs_last; bs_last = bs_now; }
+#define BS_PRINT if (t == 0 && blockIdx.x == 0) printf("block stamps: pivots %lld | y %llu rc %llu d %llu ratio %llu update %llu books %llu outer %llu (cycles per pivot)\n", (long long)pivots, bs_acc[0] / (pivots + 1), bs_acc[1] / (pivots + 1), bs_acc[2] / (pivots + 1), bs_acc[3] / (pivots + 1), bs_acc[4] / (pivots + 1), bs_acc[5] / (pivots + 1), bs_acc[6] / (pivots + 1));
+#else
+#define BS_DECL
+#define BS(k)
+#define BS_PRINT
+#endif
 template <int KIND, bool PD = false>
 __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
 {
@@ -1025,7 +1091,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     };
     if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs();
 
+    BS_DECL
     do { // one pass, or the outer loop of the primal-dual algorithm
+    BS(6)
     if (PD) {
         outer += 1;
         for (int col = t; col < n_orig; col += LPX_BLOCK) { // :405-406
@@ -1049,9 +1117,11 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         counter = 0;
         __syncthreads();
     }
+    BS(6)
     for (int64_t it = 0; it < a.maxiters; ++it) {
         counter += 1;
         int r = 0, j = 0;
+        BS(5)
         if (KIND == LPX_KIND_DUAL) { // dual_solvers.py:47-54: min(x_B), first row with x_B < 0
             double mn = (t < m) ? L.xB[t] : LPX_INF;
             int first = (t < m && mn < 0.0) ? t : 0x7FFFFFFF;
@@ -1065,8 +1135,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         }
         // ---- y = c_B @ B^-1 (primal_solvers.py:64, first product): one lane per column, i ascending
         if (t < m)
-            L.y[t] = f32 ? (double)batch_dot<float>(L.cb, 1, L.Binv + t, ldb, m) : (double)batch_dot<double>(L.cb, 1, L.Binv + t, ldb, m);
+            L.y[t] = f32 ? (double)chain_dot_va<float>(L.cb, L.Binv + t, ldb, m) : (double)chain_dot_va<double>(L.cb, L.Binv + t, ldb, m);
         __syncthreads();
+        BS(0)
         // ---- reduced costs, one lane per column (columns t, t + 256, ...), and the rule's reduction
         if (KIND == LPX_KIND_PRIMAL) { // :64-65, :135-142
             double mn = LPX_INF;
@@ -1074,8 +1145,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             for (int col = t; col < n; col += LPX_BLOCK) {
                 const int vs = L.vstate[col];
                 if (vs == LPX_VS_EXCLUDED) continue; // restricted primal of the primal-dual algorithm
-                double rc = f32 ? (double)(L.c[col] - block_dot_g<float, 32>(L.y, 1, A + col, ldA, m))
-                                : (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+                double rc = f32 ? (double)(L.c[col] - chain_dot_va<float>(L.y, A + col, ldA, m))
+                                : (double)L.c[col] - chain_dot_va<double>(L.y, A + col, ldA, m);
                 if (vs == LPX_VS_BASIC) rc = 0.0;
                 mn = fmin(mn, rc);
                 if (rc < 0.0 && col < jn) jn = col;
@@ -1137,6 +1208,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             }
             j = jn;
         }
+        BS(1)
         double sign = 1.0;
         if (KIND == LPX_KIND_BOUNDED) {
             const int vj = L.vstate[j];
@@ -1154,12 +1226,13 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                      : block_dot_g<double, 32>(L.Binv + t * ldb, 1, A + j, ldA, m);
             L.d[t] = di;
         }
+        BS(2)
         bool flip = false;
         int lstate = LPX_VS_LOWER;
         if (KIND == LPX_KIND_PRIMAL) { // ratio test :149-167, unboundedness :144-147
             double th = (t < m) ? lpx_psd(L.xB[t], di, f32) : LPX_INF, dmax = (t < m) ? di : -LPX_INF;
-            int rr = (t < m) ? t : 0x7FFFFFFF;
-            batch_argmin_max(th, rr, dmax, red);
+            int rr = 0;
+            batch_row_argmin_max(th, rr, dmax, red);
             if (dmax <= 0.0) {
                 status = LPX_PRIMAL_UNBOUNDED;
                 last_j = j;
@@ -1189,6 +1262,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         } else {
             __syncthreads(); // L.d complete
         }
+        BS(3)
         int leaving = -1;
         if (!flip) {
             // ---- eta column (:236-244), copy of the old pivot row, rank-1 update of B^-1 (:247-249)
@@ -1200,18 +1274,33 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             }
             __syncthreads();
             {
+                // 8 elements per lane at a time, every load before the first store: element by element each step waits
+                // for three dependent LDS round trips (the compiler cannot move a load above the store before it:
+                // 5.9 k cycles per pivot at m = 64, 1.4 k so)
                 int i = t / m, k = t - i * m; // incremental (row, col) walk: no division in the loop
                 const int di2 = LPX_BLOCK / m, dk2 = LPX_BLOCK - di2 * m;
-                for (int idx = t; idx < m * m; idx += LPX_BLOCK) {
-                    const double ei = L.e[i];
-                    double *p = &L.Binv[i * ldb + k];
-                    *p = (i == r) ? ei * L.rowr[k] : fma(ei, L.rowr[k], *p);
-                    i += di2; k += dk2;
-                    if (k >= m) { k -= m; i += 1; }
+                for (int idx = t; idx < m * m; idx += 8 * LPX_BLOCK) {
+                    double ei[8], rk[8], bv[8];
+                    int off[8], row[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool ok = idx + u * LPX_BLOCK < m * m;
+                        row[u] = ok ? i : -1;
+                        off[u] = ok ? i * ldb + k : 0;
+                        ei[u] = L.e[ok ? i : 0];
+                        rk[u] = L.rowr[ok ? k : 0];
+                        bv[u] = L.Binv[off[u]];
+                        i += di2; k += dk2;
+                        if (k >= m) { k -= m; i += 1; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (row[u] >= 0) L.Binv[off[u]] = (row[u] == r) ? ei[u] * rk[u] : fma(ei[u], rk[u], bv[u]);
                 }
             }
             if (KIND != LPX_KIND_BOUNDED && t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]); // :251-253
         }
+        BS(4)
         if (t == 0) {
             if (s.log && pivots < s.log_cap) {
                 int64_t *lg = s.log + pivots * 3;
@@ -1272,6 +1361,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         __syncthreads();
     }
     } while (PD && outer < a.pd_maxiters1);
+    BS(6)
+    BS_PRINT
     if (PD) {
         status = pd_status;
         counter = outer;
