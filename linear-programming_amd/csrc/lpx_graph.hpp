@@ -87,11 +87,16 @@ static int lpx_capture_iterations(hipStream_t cs, int U, F &enqueue_one, hipGrap
 }
 
 // enqueue_one(stream) enqueues exactly one iteration (returns void or an LPX_* code).  Returns LPX_OK or an error code.
+// unroll > 0: iterations per graph fixed by the caller (a chain whose kernel arguments repeat with that period);
+// whole_graphs: replay from iters >= unroll on, also while K1 event timing is on (the caller launches the timed kernel
+// itself, outside the graph).
 template <class F>
-static int lpx_run_iterations(const void *key, size_t keylen, int64_t iters, hipStream_t st, F enqueue_one)
+static int lpx_run_iterations(const void *key, size_t keylen, int64_t iters, hipStream_t st, F enqueue_one, int unroll = 0,
+                              bool whole_graphs = false)
 {
-    const int U = lpx_graph_unroll();
-    const bool use_graph = lpx_env_int("LPX_GRAPH", 1) != 0 && !lpx_k1_profile().enabled && iters >= 2 * (int64_t)U;
+    const int U = unroll > 0 ? unroll : lpx_graph_unroll();
+    const bool use_graph = lpx_env_int("LPX_GRAPH", 1) != 0 &&
+                           (whole_graphs ? iters >= (int64_t)U : (!lpx_k1_profile().enabled && iters >= 2 * (int64_t)U));
     if (use_graph) {
         LpxGraphCache &gc = lpx_graph_cache();
         std::lock_guard<std::mutex> lock(gc.mu);

@@ -14,6 +14,8 @@
 #include "lpx_rank1.hpp"
 #include "lpx_graph.hpp"
 
+#include "lpx_tableau_blocked_decl.hpp"
+
 // ratio-test partial of the single-launch chain: one record per lookahead workgroup (<= TF_MAXLA)
 #define TF_MAXLA 64
 struct FusedPart {
@@ -33,6 +35,7 @@ struct TabWs {
     double *next[2]; // primal: {min rc, entering variable, its column slot, optimal?}; dual: the TD_* record
     int64_t *base;   // pivots at the start of the current lpx_tableau_iterate call
     double *pend;    // partitioned dual loop with lookahead: {leaving row, optimal?, min x_B} decided one pivot ahead
+    TbWs tb;         // deferred-update chain (lpx_tableau_blocked.hpp)
     int64_t bytes;
 };
 static inline char *tcarve(char *&p, int64_t bytes)
@@ -69,6 +72,18 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
     }
     w.base = (int64_t *)tcarve(p, 8 * 2);
     w.pend = (double *)tcarve(p, 8 * 4);
+    w.tb.ldr = lpx_roundup(n + 1, 2) + 2;
+    w.tb.E = (double *)tcarve(p, 8 * (m + 2) * TB_KMAX);
+    w.tb.R = (double *)tcarve(p, 8 * w.tb.ldr * TB_KMAX);
+    w.tb.rc = (double *)tcarve(p, 8 * (n + 2));
+    w.tb.xb = (double *)tcarve(p, 8 * (m + 2));
+    w.tb.prow = (int64_t *)tcarve(p, 8 * TB_KMAX);
+    w.tb.pslot = (int64_t *)tcarve(p, 8 * TB_KMAX);
+    w.tb.rowflag = (uint32_t *)tcarve(p, 4 * (m + 2));
+    w.tb.cnt = (int64_t *)tcarve(p, 8 * 2);
+    w.tb.scal = (double *)tcarve(p, 8 * 16);
+    w.tb.dbest = (double *)tcarve(p, 8 * LPX_MAXP);
+    w.tb.xbest = (double *)tcarve(p, 8 * LPX_MAXP);
     w.bytes = (int64_t)(p - (char *)base);
     return w;
 }
@@ -1326,6 +1341,90 @@ static int tableau_iterate_fused(const lpx_tableau *s, const TabWs &w, int64_t i
     return LPX_OK;
 }
 
+#include "lpx_tableau_blocked.hpp"
+
+// block size of the deferred-update chain for this tableau, 0 = not used.  The chain pays two small launches per pivot
+// and saves (KB - 1) / KB of the update's traffic: it wins once the tableau is too large to stream in a few microseconds.
+static inline int t_block_size(const lpx_tableau *s)
+{
+    int kb = lpx_env_int("LPX_TABLEAU_BLOCK", 32);
+    if (kb != 8 && kb != 16 && kb != 32) return 0;
+    const int64_t bytes = 8 * (s->m + 1) * (s->n + 1);
+    if (bytes < ((int64_t)lpx_env_int("LPX_TABLEAU_BLOCK_MIN_MB", 48) << 20)) return 0;
+    return kb;
+}
+
+template <int KB>
+static void tb_launch_flush(const TbFlushArgs &f, int nt, dim3 grid, hipStream_t st)
+{
+    if (nt) hipLaunchKernelGGL((k_tb_flush2<KB, 1, 8>), grid, dim3(TB2_THREADS), 0, st, f);
+    else hipLaunchKernelGGL((k_tb_flush2<KB, 0, 8>), grid, dim3(TB2_THREADS), 0, st, f);
+}
+
+static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
+{
+    TbArgs a{};
+    a.s = *s;
+    a.b = w.tb;
+    a.price = w.price;
+    a.ratio = w.ratio;
+    a.d = w.d;
+    a.nprice = lpx_cdiv(s->n, TB_THREADS);
+    a.nratio = lpx_cdiv(s->m + 1, TB_THREADS);
+    a.u = 0;
+    const int64_t nboot = lpx_cdiv(s->n > s->m ? s->n : s->m, TB_THREADS);
+    const int64_t nprep = lpx_cdiv(t_prep_len(s), TB_THREADS);
+    // the pass over the tableau: strips of 128 columns x bands of rows; a workgroup walks down its band 64 rows at a
+    // time, so bands are whole multiples of 64 rows, and there are enough of them for ~2500 workgroups (measured on
+    // the 20001 x 20001 tableau, tools/tb_flush_bench.hip: 1 / 4 / 16 / 32 / 63 bands -> 1.58 / 1.35 / 1.22 / 1.25 / 1.32 ms)
+    TbFlushArgs f{};
+    f.T = s->T; f.rows = s->m + 1; f.cols = s->n + 1; f.ld = s->ld; f.cond = s->slot_var != nullptr;
+    f.E = w.tb.E; f.R = w.tb.R; f.ldr = w.tb.ldr; f.pslot = w.tb.pslot; f.rowflag = w.tb.rowflag; f.cnt = w.tb.cnt;
+    const int64_t nstrips = lpx_cdiv(f.cols, TB2_COLS);
+    int64_t rpb = lpx_env_int("LPX_TB_ROWS", 0);
+    if (rpb <= 0) {
+        int64_t nbands = lpx_cdiv(2560, nstrips);
+        if (nbands < 1) nbands = 1;
+        rpb = lpx_roundup(lpx_cdiv(f.rows, nbands), 64);
+    }
+    f.rpb = rpb;
+    const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
+    const dim3 fgrid((unsigned)nstrips, (unsigned)lpx_cdiv(f.rows, rpb), 1);
+    auto flush = [&](hipStream_t q) {
+        lpx_k1_begin(q);
+        if (KB == 8) tb_launch_flush<8>(f, nt, fgrid, q);
+        else if (KB == 16) tb_launch_flush<16>(f, nt, fgrid, q);
+        else tb_launch_flush<32>(f, nt, fgrid, q);
+        lpx_k1_end(q);
+    };
+    hipLaunchKernelGGL(k_tb_boot, dim3((unsigned)nboot), dim3(TB_THREADS), 0, st, a);
+    int64_t it = 0;
+    auto one = [&](hipStream_t q) {
+        TbArgs b = a;
+        b.u = (int)(it % KB);
+        hipLaunchKernelGGL(k_tb_column, dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
+        hipLaunchKernelGGL(k_tb_prepare, dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
+        it += 1;
+    };
+    struct {
+        lpx_tableau s;
+        int kb, what;
+    } key;
+    memset(&key, 0, sizeof key);
+    key.s = *s; key.kb = KB; key.what = 5;
+    // a block = KB pivots' decisions (replayed as one graph) + one pass over the tableau
+    while (iters > 0) {
+        const int64_t k = iters < KB ? iters : KB;
+        it = 0;
+        const int rc = lpx_run_iterations(&key, sizeof key, k, st, one, KB, true);
+        if (rc) return rc;
+        flush(st);
+        iters -= k;
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
     int rc = check_tableau(s);
@@ -1334,6 +1433,7 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
     if (iters <= 0) return LPX_OK;
+    if (const int kb = t_block_size(s)) return tableau_iterate_blocked(s, w, iters, st, kb);
     if (t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");

@@ -1,0 +1,196 @@
+// lpx_tb_flush.hpp -- the one HBM-bound kernel of the deferred-update chain (lpx_tableau_blocked.hpp):
+//     T <- T with the cnt pending rank-1 updates applied to every element, in order.
+// Algorithmic bytes per launch: 16 x rows x cols (every element read once, written once) + the pending pairs
+// (8 cnt (rows + cols), re-read from L2 by every workgroup that needs them); fma per element: cnt.
+//
+// Mapping.  A workgroup owns ONE narrow strip (128 columns: one wave-width of column pairs) of a band of rows and walks
+// down it; its 8 waves take turns on groups of RG rows.  The strip's entries of the cnt pivot rows live in LDS
+// (cnt x 1 KiB), read once per group (one ds_read_b128 per update feeds 2 RG fma), so a wave's registers hold only data
+// in flight: RG rows of the tableau and their multipliers.  The multipliers e_u[i] of a row are the same for every lane:
+// each lane loads the one with its index modulo 16 (per group of 16 updates) and the fma takes it from there through a
+// DPP row broadcast.  (Tried first: pivot-row strips in registers -- 2 waves per SIMD and too little in flight; the
+// multipliers as scalar loads -- four dependent scalar-cache misses per row with no SGPRs left to hide them behind.)
+// The two special cases of an update -- the pivot row itself (x <- e * R) and the column it rewrites (x <- e) -- are
+// the same fma on an accumulator reset to -0.0 (fma(e, R, -0.0) == e * R and fma(e, 1, -0.0) == e, bit for bit): one
+// wave-uniform test per update, so no row and no column leaves the fma stream (condensed layout; the full layout's
+// unit vectors take a general path).
+#pragma once
+#include "lpx_device.hpp"
+#include "lpx_rank1.hpp"
+#include "lpx_tableau_blocked_decl.hpp"
+
+// entry (i, j) of the tableau after pending update u, from its value x before it (K1's expressions, lpx_rank1.hpp)
+__device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, double e, double ru, bool cond)
+{
+    if (is_slot) return cond ? e : (is_row ? 1.0 : 0.0); // eta column (condensed) / unit vector (full form)
+    return is_row ? e * ru : fma(e, ru, x);
+}
+
+struct TbFlushArgs {
+    double *T;
+    int64_t rows, cols, ld; // cols = n + 1 (column n is x_B); ld even
+    int cond;               // condensed layout: a rewritten column receives the eta column, else a unit vector
+    const double *E;        // rows x TB_KMAX
+    const double *R;        // TB_KMAX x ldr
+    int64_t ldr;
+    const int64_t *pslot;
+    const uint32_t *rowflag;
+    const int64_t *cnt;
+    int64_t rpb;            // rows per workgroup (band height)
+};
+
+// x += e_N * pr with e_N taken from lane N of the lane's own row of 16 lanes (DPP row_newbcast, the one DPP control the
+// 64-bit VALU ops of gfx90a+ accept): the 16 multipliers of a group sit one per lane, no scalar loads, no readlanes.
+// Same issue rate as a plain v_fmac_f64 (tools/fma_rate.hip).
+template <int N>
+__device__ __forceinline__ void tb_fmac_bcast(double &x, double e16, double pr)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(e16), "v"(pr), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ double tb_bcast(double e16)
+{
+    const long long b = __double_as_longlong(e16);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), N);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), N);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+#define TB2_THREADS 512
+#define TB2_WAVES (TB2_THREADS / 64)
+#define TB2_COLS 128
+
+// the chain of updates U .. KB-1 on a wave's group of RG rows; eg[q][g] = E[row q][16 g + lane % 16]
+template <int KB, int RG, bool FULL, int U>
+struct Tb2Chain {
+    // special: bit U set = this wave resets something before update U (a pivot row in the group, a rewritten column)
+    static __device__ __forceinline__ void fast(double (&x)[RG][2], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
+                                                uint32_t special, const uint32_t (&rf)[RG], uint32_t fm0, uint32_t fm1)
+    {
+        if (FULL || U < cnt) {
+            const d2_t pr = prs[U * 64];
+            if ((special >> U) & 1u) {
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const bool row = (rf[q] >> U) & 1u;
+                    x[q][0] = (row || ((fm0 >> U) & 1u)) ? -0.0 : x[q][0];
+                    x[q][1] = (row || ((fm1 >> U) & 1u)) ? -0.0 : x[q][1];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                tb_fmac_bcast<U % 16>(x[q][0], eg[q][U / 16], pr[0]);
+                tb_fmac_bcast<U % 16>(x[q][1], eg[q][U / 16], pr[1]);
+            }
+        }
+        Tb2Chain<KB, RG, FULL, U + 1>::fast(x, eg, prs, cnt, special, rf, fm0, fm1);
+    }
+    static __device__ __forceinline__ void slow(double (&x)[RG][2], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
+                                                const uint32_t (&rf)[RG], uint32_t fm0, uint32_t fm1, bool cond)
+    {
+        if (FULL || U < cnt) {
+            const d2_t pr = prs[U * 64];
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                const double e = tb_bcast<U % 16>(eg[q][U / 16]);
+                const bool isr = (rf[q] >> U) & 1u;
+                x[q][0] = tb_apply(x[q][0], (fm0 >> U) & 1u, isr, e, pr[0], cond);
+                x[q][1] = tb_apply(x[q][1], (fm1 >> U) & 1u, isr, e, pr[1], cond);
+            }
+        }
+        Tb2Chain<KB, RG, FULL, U + 1>::slow(x, eg, prs, cnt, rf, fm0, fm1, cond);
+    }
+};
+template <int KB, int RG, bool FULL>
+struct Tb2Chain<KB, RG, FULL, KB> {
+    static __device__ __forceinline__ void fast(double (&)[RG][2], const double (&)[RG][(KB + 15) / 16], const d2_t *, int, uint32_t,
+                                                const uint32_t (&)[RG], uint32_t, uint32_t) {}
+    static __device__ __forceinline__ void slow(double (&)[RG][2], const double (&)[RG][(KB + 15) / 16], const d2_t *, int,
+                                                const uint32_t (&)[RG], uint32_t, uint32_t, bool) {}
+};
+
+template <int KB, int NT, int RG, bool FULL>
+__device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2_t *prs, uint32_t fm0, uint32_t fm1, uint32_t fxmask,
+                                         int64_t col, bool live, int64_t row0, int64_t row1)
+{
+    constexpr int NG = (KB + 15) / 16;
+    const bool cond = a.cond != 0;
+    const int64_t ld = a.ld;
+    const int wave = threadIdx.x >> 6;
+    const double *__restrict__ El = a.E + (threadIdx.x & 15);
+    const uint32_t *__restrict__ rowflag = a.rowflag;
+    for (int64_t i0 = row0 + wave * RG; i0 < row1; i0 += TB2_WAVES * RG) {
+        double x[RG][2], eg[RG][NG];
+        uint32_t rf[RG];
+        double *p = a.T + i0 * ld + col;
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+            // rows beyond the band (ragged last group) re-read the band's last row and are not stored
+            const int64_t i = (i0 + q < row1) ? i0 + q : row1 - 1;
+            const d2_t t = lpx_ld2<NT>(a.T + i * ld + col);
+            x[q][0] = t[0];
+            x[q][1] = t[1];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) eg[q][g] = El[i * TB_KMAX + 16 * g];
+            rf[q] = rowflag[i];
+        }
+        uint32_t rfany = 0u;
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+            rf[q] = __builtin_amdgcn_readfirstlane(rf[q]);
+            rfany |= rf[q];
+        }
+        // condensed layout: every case is an fma (the strip in LDS holds 1.0 in the rewritten columns); full layout:
+        // unit vectors, general path for the groups and strips that meet one
+        if (cond) Tb2Chain<KB, RG, FULL, 0>::fast(x, eg, prs, cnt, rfany | fxmask, rf, fm0, fm1);
+        else if (rfany == 0u && fxmask == 0u) Tb2Chain<KB, RG, FULL, 0>::fast(x, eg, prs, cnt, 0u, rf, 0u, 0u);
+        else Tb2Chain<KB, RG, FULL, 0>::slow(x, eg, prs, cnt, rf, fm0, fm1, cond);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < RG; ++q)
+                if (i0 + q < row1) lpx_st2<NT>(p + q * ld, d2_t{x[q][0], x[q][1]});
+        }
+    }
+}
+
+// grid (strips of TB2_COLS columns, bands of rpb rows)
+template <int KB, int NT, int RG>
+__global__ __launch_bounds__(TB2_THREADS) void k_tb_flush2(TbFlushArgs a)
+{
+    __shared__ d2_t prs_all[KB * 64];
+    const int cnt = (int)*a.cnt;
+    if (cnt <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t col0 = (int64_t)blockIdx.x * TB2_COLS;
+    const int64_t col_own = col0 + 2 * lane;
+    // every lane stays active (a DPP broadcast from a lane that has left writes nothing): lanes beyond the last column
+    // work on column 0's data and store nothing
+    const bool live = col_own < a.cols;
+    const int64_t col = live ? col_own : 0;
+    for (int idx = threadIdx.x; idx < KB * 64; idx += TB2_THREADS) {
+        const int u = idx >> 6;
+        const int64_t c = col0 + 2 * (idx & 63);
+        d2_t v = (u < cnt && c < a.cols) ? *(const d2_t *)(a.R + u * a.ldr + c) : d2_t{0.0, 0.0};
+        if (a.cond && u < cnt) { // the column this update rewrites receives e itself: fma(e, 1, -0.0)
+            const int64_t su = a.pslot[u];
+            if (c == su) v[0] = 1.0;
+            if (c + 1 == su) v[1] = 1.0;
+        }
+        prs_all[idx] = v;
+    }
+    uint32_t fm0 = 0u, fm1 = 0u;
+    for (int u = 0; u < cnt; ++u) {
+        const int64_t su = a.pslot[u];
+        fm0 |= (uint32_t)(live && col_own == su) << u;
+        fm1 |= (uint32_t)(live && col_own + 1 == su) << u;
+    }
+    uint32_t fxmask = 0u; // wave-uniform: updates that rewrite a column of this strip
+    for (int u = 0; u < cnt; ++u)
+        if (__ballot(((fm0 | fm1) >> u) & 1u) != 0ull) fxmask |= 1u << u;
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.y * a.rpb;
+    const int64_t row1 = (row0 + a.rpb < a.rows) ? row0 + a.rpb : a.rows;
+    const d2_t *prs = prs_all + lane;
+    if (cnt == KB) tb2_walk<KB, NT, RG, true>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
+    else tb2_walk<KB, NT, RG, false>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
+}

@@ -1,0 +1,157 @@
+"""GPU parity of the tableau loop with deferred updates (lpx_tableau_blocked.hpp): KB pivots are decided from the stale
+tableau plus the pending (eta column, pivot row) pairs, then one kernel applies the KB rank-1 updates in order.  Same
+arithmetic in the same order per element, so everything must be bit-identical to the eager loops and the oracle."""
+import numpy as np
+import pytest
+
+from tests._util import assert_close, case_id, gen, load, problem_of
+
+pytestmark = pytest.mark.gpu
+
+PRIMAL = [cs for cs in load("random.json") + load("textbook.json") + load("random_large.json") + load("random_xlarge.json") + load("degenerate.json")
+          if cs["solver"] == "PrimalRevisedSimplexSolver" and not cs["ref"]["exception"]]
+
+
+def logged(cls, cap):
+    return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
+
+
+def deferred(monkeypatch, kb, rows=None):
+    monkeypatch.setenv("LPX_TABLEAU_BLOCK", str(kb))
+    monkeypatch.setenv("LPX_TABLEAU_BLOCK_MIN_MB", "0")  # at any size
+    if rows is not None:
+        monkeypatch.setenv("LPX_TB_ROWS", str(rows))
+
+
+@pytest.mark.parametrize("kb", [8, 32])
+@pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
+@pytest.mark.parametrize("cs", PRIMAL, ids=case_id)
+def test_deferred_chain_matches_reference(cs, condensed, kb, monkeypatch):
+    """Both layouts through the deferred-update chain against the reference's golden pivot sequences and results."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    deferred(monkeypatch, kb)
+    ref = cs["ref"]
+    c, A, b, basis = problem_of(cs)
+    s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis, condensed=condensed)
+    res = s.solve(cs.get("maxiters", 100))
+    assert s.pivot_log().tolist() == ref["pivots"]
+    assert res.iters == ref["iters"] and res.optimum == ref["optimum"] and res.basis.tolist() == ref["basis"]
+    if "x" in ref:
+        assert_close(res.x, ref["x"], "x")
+    assert_close(res.cost, ref["cost"], "cost")
+
+
+@pytest.mark.parametrize("kb,rows", [(8, 1), (8, 16), (16, 4), (32, 16), (32, 5)])
+@pytest.mark.parametrize("m,n,condensed", [(300, 700, True), (300, 700, False), (530, 1061, True), (64, 1200, True),
+                                           (700, 760, True), (96, 200, False)])
+def test_deferred_chain_bit_exact_vs_oracle(m, n, condensed, kb, rows, monkeypatch):
+    """Calls that end inside a block, on a block boundary and after several blocks (graph replays of whole blocks): pivot
+    log, the whole tableau, basis and column maps bit-identical to the oracle's eager loop on the same layout."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    deferred(monkeypatch, kb, rows)
+    c, A, b, basis = gen.gen_primal(m, n, 5)
+    s = logged(PrimalTableauSimplexSolver, 1024)(c, A, b, basis, condensed=condensed)
+    o = O.OracleTableau(c, A, b, basis, condensed=condensed, log_cap=1024)
+    done = 0
+    for k in (1, 2, 5, 64, 33, 100):
+        res = s.solve(k)
+        r = o.solve(k)
+        done += min(k, r.iters)
+        assert s.pivot_log().tolist() == o.log[:len(s.pivot_log())].tolist()
+        w = o.nslots + 1
+        T = s._engine.T.cpu().numpy()
+        assert np.array_equal(T[:, :w], o.T[:, :w])
+        assert res.basis.tolist() == r.basis.tolist() and res.iters == r.iters and np.array_equal(res.x, r.x)
+        assert_close(res.cost, r.cost, "cost")  # dot(c, x): the device sums it as a tree, the oracle in index order
+        if condensed:
+            assert np.array_equal(s._engine.slot_var.cpu().numpy(), o.slot_var)
+
+
+@pytest.mark.parametrize("kb", [8, 32])
+def test_deferred_chain_equals_the_eager_chains_bit_for_bit(kb, monkeypatch):
+    """The same LP through the deferred chain and through the in-place three-kernel chain: identical tableaus."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    c, A, b, basis = gen.gen_primal(400, 900, 3)
+    monkeypatch.setenv("LPX_TABLEAU_BLOCK", "0")
+    monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+    eager = logged(PrimalTableauSimplexSolver, 512)(c, A, b, basis)
+    r0 = eager.solve(150)
+    deferred(monkeypatch, kb)
+    s = logged(PrimalTableauSimplexSolver, 512)(c, A, b, basis)
+    r1 = s.solve(150)
+    assert s.pivot_log().tolist() == eager.pivot_log().tolist()
+    assert bool((s._engine.T == eager._engine.T).all())
+    assert np.array_equal(r0.x, r1.x) and r0.cost == r1.cost and r0.iters == r1.iters
+
+
+@pytest.mark.parametrize("kb", [8, 32])
+def test_deferred_chain_runs_to_the_optimum_and_stays_there(kb, monkeypatch):
+    """Full solve (termination in the middle of a block, inside a replayed graph), then a second solve() on the optimal
+    state: iters == 1, nothing moves (tests/test_primal_base_solvers.py:24-34's re-entrancy)."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    deferred(monkeypatch, kb)
+    c, A, b, basis = gen.gen_primal(128, 256, 0)
+    s = logged(PrimalTableauSimplexSolver, 1024)(c, A, b, basis)
+    res = s.solve(100000)
+    o = O.OracleTableau(c, A, b, basis, condensed=True, log_cap=1024)
+    want = o.solve(100000)
+    assert res.optimum and res.iters == want.iters and s.pivot_log().tolist() == want.log.tolist()
+    assert np.array_equal(res.x, want.x)
+    assert_close(res.cost, want.cost, "cost")
+    w = o.nslots + 1
+    assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
+    T0 = s._engine.T.clone()
+    again = s.solve(100)
+    assert again.optimum and again.iters == 1 and bool((s._engine.T == T0).all())
+
+
+def test_deferred_chain_unbounded_inside_a_block(monkeypatch):
+    """LPs that turn out unbounded after some pivots: the pending updates of the unfinished block are applied, the
+    state equals the oracle's at the point where it stops."""
+    from linprog_amd import exceptions
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    deferred(monkeypatch, 8)
+    found = 0
+    for seed in range(60):
+        c, A, b, basis = gen.gen_primal(24, 60, seed)
+        A, c = A.copy(), c.copy()
+        j = 30 + seed % 6  # a late structural column that can never block: entered only after the ones before it
+        A[:, j] = -np.abs(A[:, j]) - 0.5
+        c[j] = -abs(c[j]) - 1.0
+        o = O.OracleTableau(c, A, b, basis, condensed=True, log_cap=256)
+        r = o.solve(1000)
+        if r.status != O.PRIMAL_UNBOUNDED or r.pivots < 3:
+            continue
+        s = logged(PrimalTableauSimplexSolver, 256)(c, A, b, basis)
+        with pytest.raises(exceptions.PrimalIsUnboundedError):
+            s.solve(1000)
+        assert s.pivot_log().tolist() == r.log.tolist()
+        w = o.nslots + 1
+        assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
+        found += 1
+        if found == 3:
+            break
+    assert found > 0, "no generated LP went unbounded after a few pivots"
+
+
+@pytest.mark.parametrize("m,n,seed", [(64, 128, 1), (200, 520, 2), (600, 1300, 3)])
+def test_deferred_chain_dantzig_opt_in_matches_oracle(m, n, seed, monkeypatch):
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    deferred(monkeypatch, 16)
+    c, A, b, basis = gen.gen_primal(m, n, seed)
+    s = logged(PrimalTableauSimplexSolver, 4096)(c, A, b, basis, pricing="dantzig")
+    o = O.OracleTableau(c, A, b, basis, condensed=True, log_cap=4096, pricing=1)
+    res, want = s.solve(300), o.solve(300)
+    assert s.pivot_log().tolist() == want.log.tolist() and res.iters == want.iters
+    w = o.nslots + 1
+    assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
