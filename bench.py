@@ -3,14 +3,20 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tableau|tableau1k|batch]
 
-A "step" is one simplex pivot (pricing scan -> column gather + ratio test -> eta/prepare -> rank-1 update) of
-the tableau-form loop on BASELINE.json's metric configuration: gen_primal_columns(m=20000, n=40000, seed 0),
-fp64 tableau (20001 x 40001 doubles = 6.4 GB) resident in HBM, slack starting basis.  N=1: unpartitioned.
-N>1: the tableau is column-partitioned over the N ranks (one process per GPU, torch.distributed / RCCL) and
-every pivot does one all-gather of the ranks' proposals ("scaling": "strong", total work fixed).
-The K timed pivots are enqueued back to back with no host synchronisation.
+The workload is BASELINE.json's metric configuration: gen_primal_columns(m=20000, n=40000, seed 0), fp64 tableau
+resident in HBM (condensed: the 20001 x 20001 nonbasic part, 3.2 GB), slack starting basis, the reference's pivot rules.
+A "step" is ONE PASS OF THE HOT PATH OVER THE TABLEAU.  The large-tableau loop defers its updates
+(lpx_tableau_blocked.hpp): the decisions of 32 pivots (pricing -> column + ratio test -> eta / pivot row) are taken
+from the stale tableau plus the pending (eta column, pivot row) pairs, then one kernel streams the tableau through HBM
+once and applies the 32 rank-1 updates to every element in order -- so a step is 32 pivots (`config.pivots_per_step`),
+`value` is pivots/s = steps x pivots_per_step / time, and every pivot is the reference's pivot (the run is parity-gated
+against the oracle's eager loop).  Tableaus that run one update per pivot (the 1000 x 2000 leg, N > 1) have
+pivots_per_step = 1 or do 32 eager pivots per step.  N=1: unpartitioned.  N>1: the tableau is column-partitioned over
+the N ranks (one process per GPU, torch.distributed / RCCL) and every pivot does one all-gather of the ranks'
+proposals ("scaling": "strong", total work fixed).  The timed steps are enqueued back to back with no host
+synchronisation.
 
-Rank 0 prints ONE JSON line with `roofline` (K1 = rank-1 update kernel, HIP events on the launch stream) and,
+Rank 0 prints ONE JSON line with `roofline` (the kernel that streams the tableau, HIP events on the launch stream) and,
 at N=1, `cpu_baseline` (the oracle's tableau loop on the host cores over a bounded number of pivots of the
 same workload; its pivot log is also the parity check of the GPU run's first pivots).
 """
@@ -31,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="tableau", choices=["tableau", "tableau1k", "batch", "revised1k", "revised10k", "revised20k", "dual10k", "dual1k", "config5"])
     ap.add_argument("--cpu-pivots", type=int, default=None, help="pivots of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
@@ -123,7 +129,7 @@ def main():
     # default: the headline leg (20000 x 40000 tableau) and, in the same JSON line, the metric's other legs as nested
     # records with their own roofline / cpu_baseline: "batch" = config 3 (4096 LPs of 64 x 128, sharded over the ranks),
     # "tableau1k" = config 2 (1000 x 2000, one GPU).  --headline-only skips the nested legs.
-    out = bench_tableau(args, rank, world, group, args.m or 20000, args.n or 40000, args.steps, args.warmup)
+    out = bench_tableau(args, rank, world, group, args.m or 20000, args.n or 40000, args.steps, args.warmup, blocks=True)
     if not args.headline_only and not (args.m or args.n):
         import torch
 
@@ -138,8 +144,13 @@ def main():
     finish(out)
 
 
-def bench_tableau(args, rank, world, group, m, n, K, W):
-    """One leg: K timed pivots of the tableau loop on gen_primal_columns(m, n).  Returns the record (every rank)."""
+FP64_FMA_PEAK = 78.6e12 / 2  # MI355X_MICROARCH.md: 78.6 TFLOP/s vector fp64 = 39.3 T fma/s
+
+
+def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
+    """One leg: K timed steps of the tableau loop on gen_primal_columns(m, n).  blocks: a step is one pass over the
+    tableau = 32 pivots (the deferred-update block; 32 eager pivots where the loop runs one update per pivot); else a
+    step is one pivot.  Returns the record (every rank)."""
     import ctypes as C
 
     import torch
@@ -156,13 +167,18 @@ def bench_tableau(args, rank, world, group, m, n, K, W):
     j0, j1 = ncarry * rank // world, ncarry * (rank + 1) // world
     t_setup = time.time()
     A_cols, b, c, basis = problems.gen_primal_columns(m, n, args.seed, j0, j1)
-    Solver = type("BenchTableau", (PrimalTableauSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
+    PPS = 32 if blocks else 1  # pivots per step
+    Solver = type("BenchTableau", (PrimalTableauSimplexSolver,), {"_LOG_CAP": PPS * (W + 2 * K) + 8})
     solver = Solver(c, A_cols, b, basis, group=group, columns=(j0, j1), n_global=n)
     eng = solver._engine
     lib = _lib.load()
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
-    one_launch = eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
+    kb = int(lib.lpx_tableau_block_size(C.byref(eng.s))) if group is None else 0  # pivots per pass over T, 0: eager
+    if blocks and kb not in (0, PPS):
+        PPS = kb
+    one_launch = kb == 0 and eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
+    K_piv, W_piv = K * PPS, W * PPS
 
     def barrier():
         if group is not None:
@@ -174,18 +190,18 @@ def bench_tableau(args, rank, world, group, m, n, K, W):
     # is timed in a separate eager pass of further pivots afterwards.
     events_in_timed = m >= 10000 or group is not None
     _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, torch.cuda.current_stream().cuda_stream))
-    eng.enqueue(W)
+    eng.enqueue(W_piv)
     barrier()
     if events_in_timed:
         _lib.check(lib.lpx_profile_k1(1))
     barrier()
     t0 = time.perf_counter()
-    eng.enqueue(K)
+    eng.enqueue(K_piv)
     barrier()
     dt = time.perf_counter() - t0
     extra = 0
     if not events_in_timed:
-        extra = min(K, 500)
+        extra = min(K_piv, 500)
         _lib.check(lib.lpx_profile_k1(1))
         eng.enqueue(extra)
         barrier()
@@ -198,8 +214,8 @@ def bench_tableau(args, rank, world, group, m, n, K, W):
     _lib.check(lib.lpx_profile_k1(0))
     ctrl = eng.read_ctrl()
     pivots_done = int(ctrl.pivots)
-    if pivots_done != W + K + extra or ctrl.status != _lib.RUNNING:
-        sys.exit(f"bench invalid: {pivots_done} pivots done of {W + K + extra}, status {ctrl.status}")
+    if pivots_done != W_piv + K_piv + extra or ctrl.status != _lib.RUNNING:
+        sys.exit(f"bench invalid: {pivots_done} pivots done of {W_piv + K_piv + extra}, status {ctrl.status}")
 
     # roofline of the update kernel on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
     n_loc = j1 - j0
@@ -207,20 +223,20 @@ def bench_tableau(args, rank, world, group, m, n, K, W):
     k1_avg_s = (k1_ms.value / 1e3) / max(1, k1_n.value)
     achieved = bytes_per_launch / k1_avg_s / 1e9
     traffic = traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "tb_flush_traffic.json" if kb else "k1_traffic.json")
     if os.path.exists(tpath) and m == 20000 and n == 40000 and world == 1:
         try:
             rec = json.load(open(tpath))
             # the PMC figure belongs to one layout: use it only for the layout it was measured on
             if 0.9 * bytes_per_launch <= rec.get("hbm_bytes_per_launch", 0) <= 1.2 * bytes_per_launch:
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = (f"NOT measured in this run: read from profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                traffic_src = (f"NOT measured in this run: read from profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / "
                                f"WRITE_SIZE passes of this command, tag {rec.get('tag')}: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)")
         except Exception:
             traffic = None
     out = {
         "metric": f"simplex pivots/sec ({m}x{n} fp64 tableau)",
-        "value": K / dt,
+        "value": K_piv / dt,
         "unit": "pivots/s",
         "n_gpus": world,
         "steps": K,
@@ -236,18 +252,37 @@ def bench_tableau(args, rank, world, group, m, n, K, W):
                    "m": m, "n": n,
                    "form": "condensed tableau: (m+1) x (n-m+1), the nonbasic columns and x_B (basic columns are unit "
                            "vectors no pivot changes)" if condensed else "full tableau: (m+1) x (n+1)",
-                   "launches_per_pivot": 1 if one_launch else 3,
+                   "step": (f"one pass of the hot path over the tableau: the decisions of {PPS} pivots from the stale tableau "
+                            f"plus the pending (eta column, pivot row) pairs, then ONE kernel applies the {PPS} rank-1 updates "
+                            f"to every element in order (deferred updates, bit-identical to one update per pivot)") if kb
+                   else (f"{PPS} pivots, one rank-1 update of the whole tableau each" if PPS > 1 else "one pivot"),
+                   "pivots_per_step": PPS, "pivots_timed": K_piv, "us_per_pivot": dt / K_piv * 1e6,
+                   "launches_per_pivot": (2 + 1.0 / kb) if kb else (1 if one_launch else 3),
                    "partition": f"columns/{world}",
                    "setup_s": round(t_setup, 2)},
-        "roofline": {"bound": "hbm", "kernel": "k_t_fused (update + next pivot's pricing / column / ratio test, two buffers)"
+        "roofline": {"bound": "hbm", "kernel": "k_tb_flush2 (the pass that applies a block of pending rank-1 updates)" if kb
+                     else "k_t_fused (update + next pivot's pricing / column / ratio test, two buffers)"
                      if one_launch else "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": bytes_per_launch, "layout_bytes_full": 16.0 * (m + 1) * (n + 1),
                      "avg_launch_ms": k1_avg_s * 1e3, "launches": k1_n.value,
                      "k1_timing": "HIP events in the timed region" if events_in_timed
                      else "HIP events in a separate eager pass (timed region replays hipGraphs)",
-                     "whole_pivot_GBs": 16.0 * (m + 1) * (ncarry + 1) * K / dt / 1e9},
+                     "whole_pivot_GBs": 16.0 * (m + 1) * (ncarry + 1) * K_piv / dt / 1e9},
     }
+    if kb:
+        r = out["roofline"]
+        del r["whole_pivot_GBs"]
+        r["pivots_per_launch"] = kb
+        r["note"] = (f"`achieved` = the 16 B per element this kernel really moves (each element read once, written once per "
+                     f"launch) / its launch time.  One launch carries {kb} pivots, so SURVEY 8(d)'s per-pivot figure "
+                     f"(16 (m+1)(n+1) B per pivot) is NOT what reaches HBM any more: see `per_pivot_formula_GBs`, an "
+                     f"equivalent rate, not a bandwidth")
+        r["per_pivot_formula_GBs"] = bytes_per_launch * K_piv / dt / 1e9
+        fma = float(kb) * (m + 1) * (n_loc + 1) / k1_avg_s
+        r["valu"] = {"fma_per_s": fma, "peak_fma_per_s": FP64_FMA_PEAK, "frac": fma / FP64_FMA_PEAK,
+                     "note": f"{kb} fp64 fma per element and launch against the vector fp64 peak"}
+        r["share_of_step"] = k1_ms.value / 1e3 / max(1, k1_n.value) * k1_n.value / dt
     if not events_in_timed:
         out["roofline"]["note"] = ("launch/latency-bound size (the tableau is " + f"{8e-6 * (m + 1) * (n_loc + 1):.0f}"
                                    " MB: Infinity-Cache resident): the fraction of HBM peak is reported, not claimed as a "
@@ -274,7 +309,7 @@ def cpu_baseline(args, m, n, A, b, c, basis, solver, condensed, kc=None):
     if kc is None:
         kc = args.cpu_pivots
     if kc is None:
-        kc = 300 if m >= 10000 else 4000  # ~10 s of host work at the headline size
+        kc = 640 if m >= 10000 else 4000  # ~10 s of host work at the headline size
     if kc <= 0:
         return None
     os.environ["OMP_NUM_THREADS"] = str(cores)

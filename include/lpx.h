@@ -246,8 +246,16 @@ int lpx_pd_solve_small(const lpx_revised *s, double *y, const double *c64, int64
 
 /* ----------------------------------------------------------------------------- tableau-form solver loop */
 int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
-/* `iters` primal iterations on an unpartitioned tableau (same rules as LPX_KIND_PRIMAL). */
+/* `iters` primal iterations on an unpartitioned tableau (same rules as LPX_KIND_PRIMAL: primal_solvers.py:135-167,
+ * :176-263).  Large tableaus run with DEFERRED updates (lpx_tableau_blocked.hpp): the decisions of up to
+ * lpx_tableau_block_size() pivots are taken from the stale tableau plus the pending (eta column, pivot row) pairs, then
+ * one pass over T applies those rank-1 updates to every element in order -- the arithmetic of :247-253 element by
+ * element, bit for bit, with 1/block of the HBM traffic.  T holds the current state whenever a call returns. */
 int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream);
+/* Pivots per pass over the tableau that lpx_tableau_iterate uses for this state (LPX_TABLEAU_BLOCK, default 32, for
+ * tableaus of at least LPX_TABLEAU_BLOCK_MIN_MB, default 48), or 0: one update per pivot.  No counterpart in the
+ * reference (it recomputes from B^-1 every iteration); a scheduling parameter, not a numerical one. */
+int64_t lpx_tableau_block_size(const lpx_tableau *s);
 /* Column-partitioned step, part 1: local pricing over owned columns and candidate pivot column.
  * sendbuf[0] = local min rc, sendbuf[1] = global index of the first owned column with rc<0 (or 2^62),
  * sendbuf[2 .. 2+m] = that column of T (m entries + its reduced cost).  Length lpx_tableau_msg_len(m). */

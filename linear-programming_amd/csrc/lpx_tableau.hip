@@ -74,6 +74,8 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
     w.pend = (double *)tcarve(p, 8 * 4);
     w.tb.ldr = lpx_roundup(n + 1, 2) + 2;
     w.tb.E = (double *)tcarve(p, 8 * (m + 2) * TB_KMAX);
+    w.tb.lde = lpx_roundup(m + 2, 2);
+    w.tb.Et = (double *)tcarve(p, 8 * w.tb.lde * TB_KMAX);
     w.tb.R = (double *)tcarve(p, 8 * w.tb.ldr * TB_KMAX);
     w.tb.rc = (double *)tcarve(p, 8 * (n + 2));
     w.tb.xb = (double *)tcarve(p, 8 * (m + 2));
@@ -1354,11 +1356,11 @@ static inline int t_block_size(const lpx_tableau *s)
     return kb;
 }
 
-template <int KB>
-static void tb_launch_flush(const TbFlushArgs &f, int nt, dim3 grid, hipStream_t st)
+extern "C" int64_t lpx_tableau_block_size(const lpx_tableau *s)
 {
-    if (nt) hipLaunchKernelGGL((k_tb_flush2<KB, 1, 8>), grid, dim3(TB2_THREADS), 0, st, f);
-    else hipLaunchKernelGGL((k_tb_flush2<KB, 0, 8>), grid, dim3(TB2_THREADS), 0, st, f);
+    if (s == nullptr || s->m <= 0 || s->n <= 0) return 0;
+    if (!(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n))) return 0; // partitioned: one update per pivot
+    return t_block_size(s);
 }
 
 static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
@@ -1389,12 +1391,9 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
     }
     f.rpb = rpb;
     const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
-    const dim3 fgrid((unsigned)nstrips, (unsigned)lpx_cdiv(f.rows, rpb), 1);
     auto flush = [&](hipStream_t q) {
         lpx_k1_begin(q);
-        if (KB == 8) tb_launch_flush<8>(f, nt, fgrid, q);
-        else if (KB == 16) tb_launch_flush<16>(f, nt, fgrid, q);
-        else tb_launch_flush<32>(f, nt, fgrid, q);
+        lpx_tb_flush_launch(f, KB, nt, q);
         lpx_k1_end(q);
     };
     hipLaunchKernelGGL(k_tb_boot, dim3((unsigned)nboot), dim3(TB_THREADS), 0, st, a);

@@ -32,7 +32,16 @@
 #pragma once
 
 #include "lpx_tableau_blocked_decl.hpp"
-#include "lpx_tb_flush.hpp"
+
+#ifndef LPX_TB_APPLY_DEFINED
+#define LPX_TB_APPLY_DEFINED
+// entry (i, j) of the tableau after pending update u, from its value x before it (K1's expressions, lpx_rank1.hpp)
+__device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, double e, double ru, bool cond)
+{
+    if (is_slot) return cond ? e : (is_row ? 1.0 : 0.0); // eta column (condensed) / unit vector (full form)
+    return is_row ? e * ru : fma(e, ru, x);
+}
+#endif
 
 struct TbArgs {
     lpx_tableau s;
@@ -42,7 +51,15 @@ struct TbArgs {
     double *d;
     int64_t nprice, nratio;
     int u;
+    // column-partitioned tableau: this rank's proposal (written) / the gathered proposals of all ranks (read)
+    double *sendbuf;
+    const double *recv;
+    int64_t nranks, msg;
 };
+// k_tb_column's three roles
+#define TB_LOCAL 0   /* unpartitioned: entering decision from the pricing partials, column, ratio partials */
+#define TB_PROPOSE 1 /* partitioned, before the exchange: local candidate and its column -> sendbuf */
+#define TB_SELECT 2  /* partitioned, after the exchange: global entering decision, the winner's column, ratio partials */
 
 // pricing candidate of one column (first-negative rule or opt-in Dantzig), as k_t_price
 struct TbCand {
@@ -105,6 +122,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
 }
 
 // entering decision, column of the tableau as the u pending updates leave it, ratio-test partials
+template <int MODE>
 __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 {
     __shared__ BlockRed red;
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * TB_THREADS + tid;
     const int P = a.u;
-    if (P == 0) { // a new block: nothing pending (also after the loop has ended: the flush then applies nothing)
+    if (P == 0 && MODE != TB_SELECT) { // a new block: nothing pending (also after the loop has ended: the flush then applies nothing)
         if (i <= s.m) a.b.rowflag[i] = 0u;
         if (i == 0) *a.b.cnt = 0;
     }
@@ -122,35 +140,62 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     const int32_t status = ctrl->status;
     const bool f32 = ctrl->f32_phase != 0;
     const bool in = i < s.m, inm = i <= s.m;
-    const double xi = in ? a.b.xb[i] : 0.0;
-    const int64_t bvi = in ? s.basis[i] : -1;
+    const double xi = (in && MODE != TB_PROPOSE) ? a.b.xb[i] : 0.0;
+    const int64_t bvi = (in && MODE != TB_PROPOSE) ? s.basis[i] : -1;
     double e[TB_KMAX];
-    {
-        const d2_t *Ei = (const d2_t *)(a.b.E + (inm ? i : 0) * TB_KMAX);
+    if (MODE != TB_SELECT) {
+        const double *Eti = a.b.Et + (inm ? i : 0); // coalesced over the rows of the workgroup
 #pragma unroll
-        for (int u = 0; u < TB_KMAX; u += 2) {
-            d2_t v{0.0, 0.0};
-            if (u < P) v = Ei[u >> 1];
-            e[u] = v[0];
-            e[u + 1] = v[1];
-        }
+        for (int u = 0; u < TB_KMAX; ++u) e[u] = (u < P) ? Eti[u * a.b.lde] : 0.0;
     }
     if (status != LPX_RUNNING) return;
     // entering variable (primal_solvers.py:135-142) and its column slot
     TbCand c{LPX_INF, LPX_NOIDX, -1};
-    for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
-        const double v = a.price.v0[k];
-        const int64_t id = a.price.i0[k], sl = a.price.i1[k];
-        if (s.pricing == LPX_PRICE_DANTZIG) {
-            if (vi_less(v, id, c.mn, c.var)) c = TbCand{v, id, sl};
-        } else {
-            c.mn = fmin(c.mn, v);
-            if (id < c.var) { c.var = id; c.slot = sl; }
+    int64_t win = 0;
+    if (MODE == TB_SELECT) { // lowest global index over the ranks' candidates (a handful of ranks: every thread scans them)
+        for (int64_t g = 0; g < a.nranks; ++g) {
+            const double v = a.recv[g * a.msg];
+            const int64_t idx = (int64_t)a.recv[g * a.msg + 1]; // exact: ids < 2^53, LPX_NOIDX = 2^62
+            if (s.pricing == LPX_PRICE_DANTZIG) {
+                if (vi_less(v, idx, c.mn, c.var)) { c.mn = v; c.var = idx; win = g; }
+            } else {
+                c.mn = fmin(c.mn, v);
+                if (idx < c.var) { c.var = idx; win = g; }
+            }
         }
+        c.slot = (c.var == LPX_NOIDX) ? -1 : t_slot(s, c.var); // -1: the column lives on another rank
+    } else {
+        for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
+            const double v = a.price.v0[k];
+            const int64_t id = a.price.i0[k], sl = a.price.i1[k];
+            if (s.pricing == LPX_PRICE_DANTZIG) {
+                if (vi_less(v, id, c.mn, c.var)) c = TbCand{v, id, sl};
+            } else {
+                c.mn = fmin(c.mn, v);
+                if (id < c.var) { c.var = id; c.slot = sl; }
+            }
+        }
+        c = tb_price_reduce(s.pricing, c, red, &sh_slot);
     }
-    c = tb_price_reduce(s.pricing, c, red, &sh_slot);
-    const bool opt = lpx_is_optimal_min(c.mn);
     const int64_t slot = c.slot;
+    const bool cond = s.slot_var != nullptr;
+    if (MODE == TB_PROPOSE) { // (local min rc, first owned candidate, its column as the pending updates leave it)
+        if (i == 0) {
+            a.sendbuf[0] = c.mn;
+            a.sendbuf[1] = (double)c.var;
+        }
+        if (!inm) return;
+        double di = 0.0;
+        if (c.var != LPX_NOIDX) {
+            di = s.T[i * s.ld + slot];
+#pragma unroll
+            for (int u = 0; u < TB_KMAX; ++u)
+                if (u < P) di = tb_apply(di, slot == a.b.pslot[u], i == a.b.prow[u], e[u], a.b.R[u * a.b.ldr + slot], cond);
+        }
+        a.sendbuf[2 + i] = di;
+        return;
+    }
+    const bool opt = lpx_is_optimal_min(c.mn);
     if (blockIdx.x == 0 && tid == 0) {
         ctrl->counter += 1;
         ctrl->price_val = c.mn;
@@ -161,9 +206,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         }
     }
     if (opt) return;
-    const bool cond = s.slot_var != nullptr;
     double di = 0.0;
-    if (inm) {
+    if (MODE == TB_SELECT) {
+        if (inm) {
+            di = a.recv[win * a.msg + 2 + i];
+            a.d[i] = di;
+        }
+    } else if (inm) {
         di = s.T[i * s.ld + slot];
         double ru[TB_KMAX];
         int64_t pu[TB_KMAX], su[TB_KMAX];
@@ -267,6 +316,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     if (g <= m) {
         const double eg = (g == r) ? 1.0 / dr : (-dg) / dr; // e[m] eliminates rc_j
         a.b.E[g * TB_KMAX + P] = eg;
+        a.b.Et[P * a.b.lde + g] = eg;
         if (g < m) a.b.xb[g] = (g == r) ? eg * xr : fma(eg, xr, xg);
     }
     // row r of the tableau as the P pending updates leave it: the old pivot row of this update

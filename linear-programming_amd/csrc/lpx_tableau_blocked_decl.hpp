@@ -6,7 +6,9 @@
 #define TB_THREADS 256
 
 struct TbWs {
-    double *E;         // (m + 2) x TB_KMAX: E[i][u] = eta column of pending update u, row i
+    double *E;         // (m + 2) x TB_KMAX: E[i][u] = eta column of pending update u, row i (the pass over T reads rows)
+    double *Et;        // TB_KMAX x lde: the same, transposed (the column kernel reads E[.][u] for its rows, coalesced)
+    int64_t lde;
     double *R;         // TB_KMAX x ldr: R[u][j] = row r_u of the tableau as pending updates 0..u-1 leave it
     int64_t ldr;
     double *rc;        // n: reduced-cost row, current
@@ -18,3 +20,22 @@ struct TbWs {
     double *scal;      // [0] column slot of the entering variable of the pivot in flight
     double *dbest, *xbest; // ratio partials' payload: entering-column entry and x_B of the partial's argmin row
 };
+
+// the pass over the tableau (lpx_tb_flush.hpp, compiled in lpx_tb_flush.hip)
+struct TbFlushArgs {
+    double *T;
+    int64_t rows, cols, ld; // cols = n + 1 (column n is x_B); ld even
+    int cond;               // condensed layout: a rewritten column receives the eta column, else a unit vector
+    const double *E;        // rows x TB_KMAX
+    const double *R;        // TB_KMAX x ldr
+    int64_t ldr;
+    const int64_t *pslot;
+    const uint32_t *rowflag;
+    const int64_t *cnt;
+    int64_t rpb;            // rows per workgroup (band height)
+};
+#define TB2_THREADS 512
+#define TB2_WAVES (TB2_THREADS / 64)
+#define TB2_COLS 128
+// kb in {8, 16, 32}; nt: non-temporal loads / stores; grid = (strips of TB2_COLS columns, bands of rpb rows)
+void lpx_tb_flush_launch(const TbFlushArgs &f, int kb, int nt, void *stream);

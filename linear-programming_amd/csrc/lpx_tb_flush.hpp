@@ -19,25 +19,15 @@
 #include "lpx_rank1.hpp"
 #include "lpx_tableau_blocked_decl.hpp"
 
+#ifndef LPX_TB_APPLY_DEFINED
+#define LPX_TB_APPLY_DEFINED
 // entry (i, j) of the tableau after pending update u, from its value x before it (K1's expressions, lpx_rank1.hpp)
 __device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, double e, double ru, bool cond)
 {
     if (is_slot) return cond ? e : (is_row ? 1.0 : 0.0); // eta column (condensed) / unit vector (full form)
     return is_row ? e * ru : fma(e, ru, x);
 }
-
-struct TbFlushArgs {
-    double *T;
-    int64_t rows, cols, ld; // cols = n + 1 (column n is x_B); ld even
-    int cond;               // condensed layout: a rewritten column receives the eta column, else a unit vector
-    const double *E;        // rows x TB_KMAX
-    const double *R;        // TB_KMAX x ldr
-    int64_t ldr;
-    const int64_t *pslot;
-    const uint32_t *rowflag;
-    const int64_t *cnt;
-    int64_t rpb;            // rows per workgroup (band height)
-};
+#endif
 
 // x += e_N * pr with e_N taken from lane N of the lane's own row of 16 lanes (DPP row_newbcast, the one DPP control the
 // 64-bit VALU ops of gfx90a+ accept): the 16 multipliers of a group sit one per lane, no scalar loads, no readlanes.
@@ -55,10 +45,6 @@ __device__ __forceinline__ double tb_bcast(double e16)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), N);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-
-#define TB2_THREADS 512
-#define TB2_WAVES (TB2_THREADS / 64)
-#define TB2_COLS 128
 
 // the chain of updates U .. KB-1 on a wave's group of RG rows; eg[q][g] = E[row q][16 g + lane % 16]
 template <int KB, int RG, bool FULL, int U>

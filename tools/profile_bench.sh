@@ -7,9 +7,9 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --cpu-pivots 0 > $OUT/bench_trace.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --headline-only --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_fetch.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --headline-only --steps 20 --warmup 2 --cpu-pivots 0 > $OUT/bench_write.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --cpu-pivots 0 > $OUT/bench_trace.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --headline-only --steps 10 --warmup 2 --cpu-pivots 0 > $OUT/bench_fetch.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --headline-only --steps 10 --warmup 2 --cpu-pivots 0 > $OUT/bench_write.log 2>&1 || exit 1
 LPX_GRAPH=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tableau1k -- python3 bench.py --workload tableau1k --steps 2000 --warmup 50 --cpu-pivots 0 > $OUT/bench_tableau1k_trace.log 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --workload tableau1k --steps 4000 --warmup 100 > $OUT/bench_tableau1k.json 2>> $OUT/bench_default.err || exit 1
