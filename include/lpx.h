@@ -274,6 +274,20 @@ int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, int64_t nran
 int lpx_tableau_commit_begin(const lpx_tableau *s, const double *recvbuf, int64_t nranks, double *sendbuf_next,
                              void *stream);
 int lpx_tableau_commit_update(const lpx_tableau *s, void *stream);
+/* The column-partitioned pivot with DEFERRED updates (see lpx_tableau_iterate): each rank defers the rank-1 updates of
+ * its own slice.  Same exchange as lpx_tableau_propose / _commit (same message layout, primal_solvers.py:135-167), but
+ * the proposal's column and the commit's pivot row are formed from the stale slice plus the `pending` (eta column,
+ * pivot row) pairs of the current block, and no update kernel runs until lpx_tableau_block_flush applies the block
+ * (`block` = lpx_tableau_block_size(): at most that many pivots between two flushes; flush before anything else reads T).
+ *   lpx_tableau_block_begin                    once before the first propose of a run of pivots (after the caller touched T)
+ *   lpx_tableau_block_propose(pending, send)   pending = pivots since the last flush (0 .. block-1)
+ *   all-gather of the proposals                (caller: RCCL / torch.distributed)
+ *   lpx_tableau_block_commit(pending, recv)    entering / leaving decision, eta column, bookkeeping: pending + 1 are now pending
+ *   lpx_tableau_block_flush(block)             T <- T with the pending updates applied, in order */
+int lpx_tableau_block_begin(const lpx_tableau *s, void *stream);
+int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream);
+int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream);
+int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void *stream);
 /* x[n_global-sized on rank owning..] : x_B and basis are replicated, so every rank can expand: x, cost. */
 int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
 

@@ -1359,11 +1359,10 @@ static inline int t_block_size(const lpx_tableau *s)
 extern "C" int64_t lpx_tableau_block_size(const lpx_tableau *s)
 {
     if (s == nullptr || s->m <= 0 || s->n <= 0) return 0;
-    if (!(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n))) return 0; // partitioned: one update per pivot
     return t_block_size(s);
 }
 
-static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
+static TbArgs tb_args(const lpx_tableau *s, const TabWs &w)
 {
     TbArgs a{};
     a.s = *s;
@@ -1374,11 +1373,18 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
     a.nprice = lpx_cdiv(s->n, TB_THREADS);
     a.nratio = lpx_cdiv(s->m + 1, TB_THREADS);
     a.u = 0;
+    return a;
+}
+static void tb_boot(const lpx_tableau *s, const TbArgs &a, hipStream_t st)
+{
     const int64_t nboot = lpx_cdiv(s->n > s->m ? s->n : s->m, TB_THREADS);
-    const int64_t nprep = lpx_cdiv(t_prep_len(s), TB_THREADS);
-    // the pass over the tableau: strips of 128 columns x bands of rows; a workgroup walks down its band 64 rows at a
-    // time, so bands are whole multiples of 64 rows, and there are enough of them for ~2500 workgroups (measured on
-    // the 20001 x 20001 tableau, tools/tb_flush_bench.hip: 1 / 4 / 16 / 32 / 63 bands -> 1.58 / 1.35 / 1.22 / 1.25 / 1.32 ms)
+    hipLaunchKernelGGL(k_tb_boot, dim3((unsigned)nboot), dim3(TB_THREADS), 0, st, a);
+}
+// the pass over the tableau: strips of 128 columns x bands of rows; a workgroup walks down its band 64 rows at a
+// time, so bands are whole multiples of 64 rows, and there are enough of them for ~2500 workgroups (measured on
+// the 20001 x 20001 tableau, tools/tb_flush_bench.hip: 1 / 4 / 16 / 32 / 63 bands -> 1.58 / 1.35 / 1.22 / 1.25 / 1.32 ms)
+static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q)
+{
     TbFlushArgs f{};
     f.T = s->T; f.rows = s->m + 1; f.cols = s->n + 1; f.ld = s->ld; f.cond = s->slot_var != nullptr;
     f.E = w.tb.E; f.R = w.tb.R; f.ldr = w.tb.ldr; f.pslot = w.tb.pslot; f.rowflag = w.tb.rowflag; f.cnt = w.tb.cnt;
@@ -1391,17 +1397,22 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
     }
     f.rpb = rpb;
     const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
-    auto flush = [&](hipStream_t q) {
-        lpx_k1_begin(q);
-        lpx_tb_flush_launch(f, KB, nt, q);
-        lpx_k1_end(q);
-    };
-    hipLaunchKernelGGL(k_tb_boot, dim3((unsigned)nboot), dim3(TB_THREADS), 0, st, a);
+    lpx_k1_begin(q);
+    lpx_tb_flush_launch(f, KB, nt, q);
+    lpx_k1_end(q);
+}
+
+static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
+{
+    const TbArgs a = tb_args(s, w);
+    const int64_t nprep = lpx_cdiv(t_prep_len(s), TB_THREADS);
+    auto flush = [&](hipStream_t q) { tb_flush(s, w, KB, q); };
+    tb_boot(s, a, st);
     int64_t it = 0;
     auto one = [&](hipStream_t q) {
         TbArgs b = a;
         b.u = (int)(it % KB);
-        hipLaunchKernelGGL(k_tb_column, dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
+        hipLaunchKernelGGL((k_tb_column<TB_LOCAL>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
         hipLaunchKernelGGL(k_tb_prepare, dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
         it += 1;
     };
@@ -1420,6 +1431,61 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
         flush(st);
         iters -= k;
     }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---- column-partitioned tableau with deferred updates: every rank defers the updates of its own slice.  Replicated:
+// x_B (xb[]), the eta columns (formed from the gathered winner's column) and all decisions; local: the slices of the
+// pivot rows (R), of the reduced-cost row (rc[]) and the pricing partials.  Per pivot: propose -> all-gather -> commit;
+// per block (or at the end of the caller's loop): flush.
+extern "C" int lpx_tableau_block_begin(const lpx_tableau *s, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    tb_boot(s, tb_args(s, w), (hipStream_t)stream);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    TbArgs a = tb_args(s, w);
+    a.u = (int)pending;
+    a.sendbuf = sendbuf;
+    hipLaunchKernelGGL((k_tb_column<TB_PROPOSE>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, (hipStream_t)stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
+    LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    TbArgs a = tb_args(s, w);
+    a.u = (int)pending;
+    a.recv = recvbuf;
+    a.nranks = nranks;
+    a.msg = lpx_tableau_msg_len(s->m);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_tb_column<TB_SELECT>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_tb_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), TB_THREADS)), dim3(TB_THREADS), 0, st, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(block == 8 || block == 16 || block == 32, "block size must be 8, 16 or 32");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    tb_flush(s, w, (int)block, (hipStream_t)stream);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

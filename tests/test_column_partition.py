@@ -52,6 +52,19 @@ def test_product_path_lookahead_and_kernel_variants(env):
     _run("gpu", 2, 64, 128, 2, 100000, **env)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,m,n,env", [
+    (2, 64, 128, {"LPX_TABLEAU_BLOCK": "8"}), (3, 50, 121, {"LPX_TABLEAU_BLOCK": "32"}),
+    (2, 64, 128, {"LPX_TABLEAU_BLOCK": "16", "LPX_TABLEAU_CONDENSED": "0"}),
+    (3, 50, 121, {"LPX_TABLEAU_BLOCK": "8", "LPX_TABLEAU_CONDENSED": "0"})],
+    ids=lambda v: ",".join(f"{k[12:]}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_product_path_deferred_updates(nproc, m, n, env):
+    """The column-partitioned loop with deferred updates (lpx_tableau_block_*: propose -> all-gather -> commit per pivot
+    from the stale slice plus the pending pairs, one pass over each rank's slice per block), forced on at test sizes: slack
+    and float32-inverted starting bases, column-slice construction, both layouts -- the oracle's pivot sequences."""
+    _run("gpu", nproc, m, n, 2, 100000, LPX_TABLEAU_BLOCK_MIN_MB="0", **env)
+
+
 @pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
 def test_dual_protocol_cpu_gloo(nproc, m, n):
     _run("cpu-dual", nproc, m, n, 1, 100000)
