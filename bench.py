@@ -174,7 +174,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     lib = _lib.load()
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
-    kb = int(lib.lpx_tableau_block_size(C.byref(eng.s))) if group is None else 0  # pivots per pass over T, 0: eager
+    kb = int(lib.lpx_tableau_block_size(C.byref(eng.s)))  # pivots per pass over T (this rank's slice), 0: one update per pivot
     if blocks and kb not in (0, PPS):
         PPS = kb
     one_launch = kb == 0 and eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
@@ -257,7 +257,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
                             f"to every element in order (deferred updates, bit-identical to one update per pivot)") if kb
                    else (f"{PPS} pivots, one rank-1 update of the whole tableau each" if PPS > 1 else "one pivot"),
                    "pivots_per_step": PPS, "pivots_timed": K_piv, "us_per_pivot": dt / K_piv * 1e6,
-                   "launches_per_pivot": (2 + 1.0 / kb) if kb else (1 if one_launch else 3),
+                   "launches_per_pivot": ((2 if group is None else 3) + 1.0 / kb) if kb else (1 if one_launch else 3),
                    "partition": f"columns/{world}",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_tb_flush2 (the pass that applies a block of pending rank-1 updates)" if kb

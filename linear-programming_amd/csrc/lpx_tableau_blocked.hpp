@@ -43,6 +43,14 @@ __device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, 
 }
 #endif
 
+// -DLPX_TB_STAMPS: diagnostic build, workgroup 0 prints where the two per-pivot kernels spend their time (10 ns ticks)
+#ifdef LPX_TB_STAMPS
+__device__ long long g_tb_stamp[2][16];
+#define LPX_TB_STAMP(k, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tb_stamp[k][n] = (long long)wall_clock64(); } while (0)
+#else
+#define LPX_TB_STAMP(k, n) do { } while (0)
+#endif
+
 struct TbArgs {
     lpx_tableau s;
     TbWs b;
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * TB_THREADS + tid;
     const int P = a.u;
+    LPX_TB_STAMP(0, 0);
     if (P == 0 && MODE != TB_SELECT) { // a new block: nothing pending (also after the loop has ended: the flush then applies nothing)
         if (i <= s.m) a.b.rowflag[i] = 0u;
         if (i == 0) *a.b.cnt = 0;
@@ -142,6 +151,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     const bool in = i < s.m, inm = i <= s.m;
     const double xi = (in && MODE != TB_PROPOSE) ? a.b.xb[i] : 0.0;
     const int64_t bvi = (in && MODE != TB_PROPOSE) ? s.basis[i] : -1;
+    // the pending updates' pivot rows and rewritten columns: ONE vector load each (lane l holds update l), broadcast with
+    // v_readlane in the chain -- as 2 x 32 scalar loads they missed the scalar cache one after the other (5 us at P = 31)
+    const int l32 = tid & 31;
+    const int pv = (MODE != TB_SELECT && l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2; // rows and slots < 2^31 (or -1)
+    const int sv = (MODE != TB_SELECT && l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
     double e[TB_KMAX];
     if (MODE != TB_SELECT) {
         const double *Eti = a.b.Et + (inm ? i : 0); // coalesced over the rows of the workgroup
@@ -149,6 +163,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         for (int u = 0; u < TB_KMAX; ++u) e[u] = (u < P) ? Eti[u * a.b.lde] : 0.0;
     }
     if (status != LPX_RUNNING) return;
+    LPX_TB_STAMP(0, 1);
     // entering variable (primal_solvers.py:135-142) and its column slot
     TbCand c{LPX_INF, LPX_NOIDX, -1};
     int64_t win = 0;
@@ -175,8 +190,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
                 if (id < c.var) { c.var = id; c.slot = sl; }
             }
         }
+        LPX_TB_STAMP(0, 2);
         c = tb_price_reduce(s.pricing, c, red, &sh_slot);
     }
+    LPX_TB_STAMP(0, 3);
     const int64_t slot = c.slot;
     const bool cond = s.slot_var != nullptr;
     if (MODE == TB_PROPOSE) { // (local min rc, first owned candidate, its column as the pending updates leave it)
@@ -184,15 +201,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
             a.sendbuf[0] = c.mn;
             a.sendbuf[1] = (double)c.var;
         }
-        if (!inm) return;
         double di = 0.0;
-        if (c.var != LPX_NOIDX) {
-            di = s.T[i * s.ld + slot];
+        if (c.var != LPX_NOIDX) { // workgroup-uniform
+            const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
+            di = inm ? s.T[i * s.ld + slot] : 0.0;
 #pragma unroll
             for (int u = 0; u < TB_KMAX; ++u)
-                if (u < P) di = tb_apply(di, slot == a.b.pslot[u], i == a.b.prow[u], e[u], a.b.R[u * a.b.ldr + slot], cond);
+                if (u < P)
+                    di = tb_apply(di, (int)slot == __builtin_amdgcn_readlane(sv, u), (int)i == __builtin_amdgcn_readlane(pv, u), e[u],
+                                  tf_readlane_f64(rv, u), cond);
         }
-        a.sendbuf[2 + i] = di;
+        if (inm) a.sendbuf[2 + i] = di;
         return;
     }
     const bool opt = lpx_is_optimal_min(c.mn);
@@ -212,27 +231,22 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
             di = a.recv[win * a.msg + 2 + i];
             a.d[i] = di;
         }
-    } else if (inm) {
-        di = s.T[i * s.ld + slot];
-        double ru[TB_KMAX];
-        int64_t pu[TB_KMAX], su[TB_KMAX];
-#pragma unroll
-        for (int u = 0; u < TB_KMAX; ++u) {
-            if (u < P) {
-                ru[u] = a.b.R[u * a.b.ldr + slot];
-                pu[u] = a.b.prow[u];
-                su[u] = a.b.pslot[u];
-            }
-        }
+    } else {
+        const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0; // lane l: entry `slot` of pivot row l
+        di = inm ? s.T[i * s.ld + slot] : 0.0;
 #pragma unroll
         for (int u = 0; u < TB_KMAX; ++u)
-            if (u < P) di = tb_apply(di, slot == su[u], i == pu[u], e[u], ru[u], cond);
-        a.d[i] = di; // d[m] = the entering variable's reduced cost
+            if (u < P)
+                di = tb_apply(di, (int)slot == __builtin_amdgcn_readlane(sv, u), (int)i == __builtin_amdgcn_readlane(pv, u), e[u],
+                              tf_readlane_f64(rv, u), cond);
+        if (inm) a.d[i] = di; // d[m] = the entering variable's reduced cost
     }
     // ratio test (primal_solvers.py:149-167): first minimum over this workgroup's rows, with what the winner needs
     const VI t{in ? lpx_psd(xi, di, f32) : LPX_INF, in ? i : LPX_NOIDX};
+    LPX_TB_STAMP(0, 4);
     const VI w = block_argmin(t, red);
     const double dmax = block_max(in ? di : -LPX_INF, red);
+    LPX_TB_STAMP(0, 5);
     if (tid == 0) {
         a.ratio.v1[blockIdx.x] = dmax;
         if (w.i == LPX_NOIDX) {
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         a.b.dbest[blockIdx.x] = di;
         a.b.xbest[blockIdx.x] = xi;
     }
+    LPX_TB_STAMP(0, 6);
 }
 
 // leaving row, eta column, x_B, the pivot row as the pending updates leave it, the reduced-cost row and its pricing
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int tid = threadIdx.x;
     const int64_t g = (int64_t)blockIdx.x * TB_THREADS + tid;
     const int P = a.u;
+    LPX_TB_STAMP(1, 0);
     const int64_t m = s.m, n = s.n, ncopy = lpx_roundup_dev(n + 1, 2);
     // loads whose addresses depend on nothing decided in this launch
     const int32_t status = ctrl->status;
@@ -275,15 +291,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const double dg = (g <= m) ? a.d[g] : 0.0, dm = a.d[m];
     const double xg = (g < m) ? a.b.xb[g] : 0.0;
     const int64_t varg = (g < n) ? t_var(s, g) : LPX_NOIDX;
-    int64_t pu[TB_KMAX], su[TB_KMAX];
-#pragma unroll
-    for (int u = 0; u < TB_KMAX; ++u) {
-        if (u < P) {
-            pu[u] = a.b.prow[u];
-            su[u] = a.b.pslot[u];
-        }
-    }
+    const int l32 = tid & 31; // lane l holds pending update l's pivot row / rewritten column / multiplier of row r
+    const int pv = (l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2;
+    const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
     if (status != LPX_RUNNING) return;
+    LPX_TB_STAMP(1, 1);
     // leaving row: first minimum ratio over the workgroups' partials (primal_solvers.py:166, np.argmin)
     VI best{LPX_INF, LPX_NOIDX};
     int64_t bk = -1;
@@ -294,8 +306,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         if (vi_less(v, r, best.v, best.i)) { best = VI{v, r}; bk = k; }
         dmax = fmax(dmax, a.ratio.v1[k]);
     }
+    LPX_TB_STAMP(1, 2);
     const VI w = block_argmin(best, red);
     dmax = block_max(dmax, red);
+    LPX_TB_STAMP(1, 3);
     if (dmax <= 0.0) { // primal_solvers.py:144-147
         if (g == 0) {
             ctrl->aux_val = dmax;
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int64_t r = w.i, leaving = sh_bv;
     const double dr = sh_pay[0], xr = sh_pay[1];
     const bool cond = s.slot_var != nullptr;
+    LPX_TB_STAMP(1, 4);
     // eta column (primal_solvers.py:217-245), x_B (:251-253)
     if (g <= m) {
         const double eg = (g == r) ? 1.0 / dr : (-dg) / dr; // e[m] eliminates rc_j
@@ -319,20 +334,20 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         a.b.Et[P * a.b.lde + g] = eg;
         if (g < m) a.b.xb[g] = (g == r) ? eg * xr : fma(eg, xr, xg);
     }
+    LPX_TB_STAMP(1, 5);
     // row r of the tableau as the P pending updates leave it: the old pivot row of this update
     double rowp = 0.0;
-    if (incol) {
-        rowp = s.T[r * s.ld + g];
-        const double *Er = a.b.E + r * TB_KMAX;
-        double er[TB_KMAX];
+    {
+        const double erv = (l32 < P) ? a.b.E[r * TB_KMAX + l32] : 0.0;
+        rowp = incol ? s.T[r * s.ld + g] : 0.0;
 #pragma unroll
         for (int u = 0; u < TB_KMAX; ++u)
-            if (u < P) er[u] = Er[u];
-#pragma unroll
-        for (int u = 0; u < TB_KMAX; ++u)
-            if (u < P) rowp = tb_apply(rowp, g == su[u], r == pu[u], er[u], ru[u], cond);
-        a.b.R[P * a.b.ldr + g] = rowp;
+            if (u < P)
+                rowp = tb_apply(rowp, (int)g == __builtin_amdgcn_readlane(sv, u), (int)r == __builtin_amdgcn_readlane(pv, u),
+                                tf_readlane_f64(erv, u), ru[u], cond);
+        if (incol) a.b.R[P * a.b.ldr + g] = rowp;
     }
+    LPX_TB_STAMP(1, 6);
     // the reduced-cost row after this pivot, and its pricing partial (the next pivot's entering decision)
     if ((int64_t)blockIdx.x < a.nprice) {
         TbCand c{LPX_INF, LPX_NOIDX, -1};
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
             a.price.i1[blockIdx.x] = c.slot;
         }
     }
+    LPX_TB_STAMP(1, 7);
     if (g == 0) { // bookkeeping of the basis change (primal_solvers.py:96-108, :261)
         s.basis[r] = j;
         t_swap_columns(s, j, leaving);
@@ -375,6 +391,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         a.b.pslot[P] = slot;
         a.b.rowflag[r] |= 1u << P;
         *a.b.cnt = P + 1;
+#ifdef LPX_TB_STAMPS
+        g_tb_stamp[1][8] = (long long)wall_clock64();
+        if (ctrl->pivots >= 96 && ctrl->pivots < 160 && (P == 0 || P == 15 || P == 31)) {
+            const long long *c0 = g_tb_stamp[0], *p0 = g_tb_stamp[1];
+            printf("P=%d column: status %lld | partials %lld | price reduce %lld | column+chain %lld | ratio reduce %lld | end %lld || "
+                   "gap %lld || prepare: status %lld | partials %lld | ratio reduce %lld | payload %lld | eta %lld | row chain %lld | "
+                   "rc+price reduce %lld | books %lld\n", P, c0[1] - c0[0], c0[2] - c0[1], c0[3] - c0[2], c0[4] - c0[3], c0[5] - c0[4],
+                   c0[6] - c0[5], p0[0] - c0[6], p0[1] - p0[0], p0[2] - p0[1], p0[3] - p0[2], p0[4] - p0[3], p0[5] - p0[4],
+                   p0[6] - p0[5], p0[7] - p0[6], p0[8] - p0[7]);
+        }
+#endif
     }
 }
 
