@@ -252,8 +252,8 @@ int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
  * one pass over T applies those rank-1 updates to every element in order -- the arithmetic of :247-253 element by
  * element, bit for bit, with 1/block of the HBM traffic.  T holds the current state whenever a call returns. */
 int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream);
-/* Pivots per pass over the tableau that lpx_tableau_iterate uses for this state (LPX_TABLEAU_BLOCK, default 32, for
- * tableaus of at least LPX_TABLEAU_BLOCK_MIN_MB, default 48), or 0: one update per pivot.  No counterpart in the
+/* Pivots per pass over the tableau that lpx_tableau_iterate uses for this state (LPX_TABLEAU_BLOCK: 8, 16 or 32; default
+ * 32 from 192 MiB on, else 16; for tableaus of at least LPX_TABLEAU_BLOCK_MIN_MB, default 48), or 0: one update per pivot.  No counterpart in the
  * reference (it recomputes from B^-1 every iteration); a scheduling parameter, not a numerical one. */
 int64_t lpx_tableau_block_size(const lpx_tableau *s);
 /* Column-partitioned step, part 1: local pricing over owned columns and candidate pivot column.

@@ -1349,11 +1349,13 @@ static int tableau_iterate_fused(const lpx_tableau *s, const TabWs &w, int64_t i
 // and saves (KB - 1) / KB of the update's traffic: it wins once the tableau is too large to stream in a few microseconds.
 static inline int t_block_size(const lpx_tableau *s)
 {
-    int kb = lpx_env_int("LPX_TABLEAU_BLOCK", 32);
-    if (kb != 8 && kb != 16 && kb != 32) return 0;
+    // measured on MI355X (tools/block_crossover.sh, k pivots/s, one update per pivot / blocks of 16 / of 32): 2000 x 4000
+    // 80 / 62 / 60; 3000 x 6000 41 / 57 / 57; 5000 x 10000 13 / 50 / 52; 8000 x 16000 5.7 / 38 / 43; 20000 x 40000
+    // 0.96 / - / 17.8: the chain pays ~15 us of decision kernels per pivot whatever the size
     const int64_t bytes = 8 * (s->m + 1) * (s->n + 1);
     if (bytes < ((int64_t)lpx_env_int("LPX_TABLEAU_BLOCK_MIN_MB", 48) << 20)) return 0;
-    return kb;
+    const int kb = lpx_env_int("LPX_TABLEAU_BLOCK", bytes >= ((int64_t)192 << 20) ? 32 : 16);
+    return (kb == 8 || kb == 16 || kb == 32) ? kb : 0;
 }
 
 extern "C" int64_t lpx_tableau_block_size(const lpx_tableau *s)

@@ -83,32 +83,52 @@ __device__ __forceinline__ void tb_price_one(int64_t pricing, double rc, int64_t
         if (rc < 0.0 && v < c.var) { c.var = v; c.slot = slot; }
     }
 }
-// workgroup reduction of pricing candidates; every thread returns the winner (variable ids are distinct)
-__device__ __forceinline__ TbCand tb_price_reduce(int64_t pricing, TbCand c, BlockRed &red, int64_t *sh_slot)
+// Workgroup reductions with ONE LDS exchange and ONE barrier: the whole record goes through the DPP wave reduction
+// (every lane ends with the wave's result), lane 0 of each wave publishes it, every thread combines the four.  `sh` is
+// private to the call site (never reused inside a kernel), so no barrier follows.  Ties are decided inside `op`
+// (lowest variable id / lowest row), so the result does not depend on the order of combination.
+template <typename T, typename Op>
+__device__ __forceinline__ T tb_block_reduce(T v, Op op, T *sh)
 {
-    TbCand w;
-    if (pricing == LPX_PRICE_DANTZIG) {
-        const VI t = block_argmin(VI{c.mn, c.var}, red);
-        w.mn = t.v;
-        w.var = t.i;
-    } else {
-        w.mn = block_min(c.mn, red);
-        w.var = block_imin(c.var, red);
-    }
-    if (threadIdx.x == 0) *sh_slot = -1;
+    v = wave_allreduce(v, op);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (w.var != LPX_NOIDX && c.var == w.var) *sh_slot = c.slot;
-    __syncthreads();
-    w.slot = *sh_slot;
-    __syncthreads();
-    return w;
+    T r = sh[0];
+#pragma unroll
+    for (int w = 1; w < TB_THREADS / 64; ++w) r = op(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ TbCand tb_price_reduce(int64_t pricing, TbCand c, TbCand *sh)
+{
+    // two capture-free operators (a capturing one was not inlined into the DPP reduction: 3-5 us per call)
+    if (pricing == LPX_PRICE_DANTZIG)
+        return tb_block_reduce(c, [](TbCand x, TbCand y) { return vi_less(y.mn, y.var, x.mn, x.var) ? y : x; }, sh);
+    return tb_block_reduce(c, [](TbCand x, TbCand y) {
+        TbCand t = (y.var < x.var) ? y : x; // first negative index: smallest variable id (ids are distinct)
+        t.mn = fmin(x.mn, y.mn);
+        return t;
+    }, sh);
+}
+// ratio test record: first minimum ratio with what the winner needs later (its row, entering-column entry, x_B, basic variable)
+struct TbRatio {
+    double th;
+    int64_t row;
+    double dmax, dv, xv;
+    int64_t bv;
+};
+__device__ __forceinline__ TbRatio tb_ratio_reduce(TbRatio t, TbRatio *sh)
+{
+    return tb_block_reduce(t, [](TbRatio x, TbRatio y) {
+        TbRatio u = vi_less(y.th, y.row, x.th, x.row) ? y : x;
+        u.dmax = fmax(x.dmax, y.dmax);
+        return u;
+    }, sh);
 }
 
 // start of a call: rc[] and xb[] from the tableau, pricing partials of the carried row
 __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
 {
-    __shared__ BlockRed red;
-    __shared__ int64_t sh_slot;
+    __shared__ TbCand sh_price[TB_THREADS / 64];
     const lpx_tableau &s = a.s;
     const int64_t g = (int64_t)blockIdx.x * TB_THREADS + threadIdx.x;
     if (g == 0) *a.b.cnt = 0;
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
         a.b.rc[g] = rc;
         tb_price_one(s.pricing, rc, t_var(s, g), g, c);
     }
-    c = tb_price_reduce(s.pricing, c, red, &sh_slot);
+    c = tb_price_reduce(s.pricing, c, sh_price);
     if (threadIdx.x == 0) {
         a.price.v0[blockIdx.x] = c.mn;
         a.price.i0[blockIdx.x] = c.var;
@@ -129,12 +149,28 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
     }
 }
 
+// entry i of column `slot` after the P pending updates: the column an update rewrote is a wave-uniform case, the pivot
+// row of an update is the same fma on an accumulator of -0.0 (fma(e, R, -0.0) == e * R bit for bit)
+__device__ __forceinline__ double tb_column_chain(double di, int P, int slot, int i, int sv, int pv, const double (&e)[TB_KMAX], double rv,
+                                                  bool cond)
+{
+#pragma unroll
+    for (int u = 0; u < TB_KMAX; ++u) {
+        if (u < P) {
+            const int pu = __builtin_amdgcn_readlane(pv, u);
+            if (slot == __builtin_amdgcn_readlane(sv, u)) di = cond ? e[u] : ((i == pu) ? 1.0 : 0.0);
+            else di = fma(e[u], tf_readlane_f64(rv, u), (i == pu) ? -0.0 : di);
+        }
+    }
+    return di;
+}
+
 // entering decision, column of the tableau as the u pending updates leave it, ratio-test partials
 template <int MODE>
 __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 {
-    __shared__ BlockRed red;
-    __shared__ int64_t sh_slot;
+    __shared__ TbCand sh_price[TB_THREADS / 64];
+    __shared__ TbRatio sh_ratio[TB_THREADS / 64];
     const lpx_tableau &s = a.s;
     lpx_ctrl *ctrl = s.ctrl;
     const int tid = threadIdx.x;
@@ -191,7 +227,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
             }
         }
         LPX_TB_STAMP(0, 2);
-        c = tb_price_reduce(s.pricing, c, red, &sh_slot);
+        c = tb_price_reduce(s.pricing, c, sh_price);
     }
     LPX_TB_STAMP(0, 3);
     const int64_t slot = c.slot;
@@ -205,11 +241,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         if (c.var != LPX_NOIDX) { // workgroup-uniform
             const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
             di = inm ? s.T[i * s.ld + slot] : 0.0;
-#pragma unroll
-            for (int u = 0; u < TB_KMAX; ++u)
-                if (u < P)
-                    di = tb_apply(di, (int)slot == __builtin_amdgcn_readlane(sv, u), (int)i == __builtin_amdgcn_readlane(pv, u), e[u],
-                                  tf_readlane_f64(rv, u), cond);
+            di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
         }
         if (inm) a.sendbuf[2 + i] = di;
         return;
@@ -234,32 +266,22 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     } else {
         const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0; // lane l: entry `slot` of pivot row l
         di = inm ? s.T[i * s.ld + slot] : 0.0;
-#pragma unroll
-        for (int u = 0; u < TB_KMAX; ++u)
-            if (u < P)
-                di = tb_apply(di, (int)slot == __builtin_amdgcn_readlane(sv, u), (int)i == __builtin_amdgcn_readlane(pv, u), e[u],
-                              tf_readlane_f64(rv, u), cond);
+        di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
         if (inm) a.d[i] = di; // d[m] = the entering variable's reduced cost
     }
     // ratio test (primal_solvers.py:149-167): first minimum over this workgroup's rows, with what the winner needs
-    const VI t{in ? lpx_psd(xi, di, f32) : LPX_INF, in ? i : LPX_NOIDX};
+    TbRatio t{in ? lpx_psd(xi, di, f32) : LPX_INF, in ? i : LPX_NOIDX, in ? di : -LPX_INF, di, xi, bvi};
     LPX_TB_STAMP(0, 4);
-    const VI w = block_argmin(t, red);
-    const double dmax = block_max(in ? di : -LPX_INF, red);
+    t = tb_ratio_reduce(t, sh_ratio);
     LPX_TB_STAMP(0, 5);
     if (tid == 0) {
-        a.ratio.v1[blockIdx.x] = dmax;
-        if (w.i == LPX_NOIDX) {
-            a.ratio.v0[blockIdx.x] = LPX_INF;
-            a.ratio.i0[blockIdx.x] = LPX_NOIDX;
-        }
-    }
-    if (in && i == w.i) {
-        a.ratio.v0[blockIdx.x] = w.v;
-        a.ratio.i0[blockIdx.x] = w.i;
-        a.ratio.i1[blockIdx.x] = bvi;
-        a.b.dbest[blockIdx.x] = di;
-        a.b.xbest[blockIdx.x] = xi;
+        const bool none = t.row == LPX_NOIDX;
+        a.ratio.v0[blockIdx.x] = t.th;
+        a.ratio.i0[blockIdx.x] = t.row;
+        a.ratio.v1[blockIdx.x] = t.dmax;
+        a.ratio.i1[blockIdx.x] = none ? -1 : t.bv;
+        a.b.dbest[blockIdx.x] = none ? 0.0 : t.dv;
+        a.b.xbest[blockIdx.x] = none ? 0.0 : t.xv;
     }
     LPX_TB_STAMP(0, 6);
 }
@@ -268,10 +290,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 // partials, bookkeeping
 __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
 {
-    __shared__ BlockRed red;
-    __shared__ int64_t sh_slot;
-    __shared__ double sh_pay[2];
-    __shared__ int64_t sh_bv;
+    __shared__ TbCand sh_price[TB_THREADS / 64];
+    __shared__ TbRatio sh_ratio[TB_THREADS / 64];
     const lpx_tableau &s = a.s;
     lpx_ctrl *ctrl = s.ctrl;
     const int tid = threadIdx.x;
@@ -296,20 +316,18 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
     if (status != LPX_RUNNING) return;
     LPX_TB_STAMP(1, 1);
-    // leaving row: first minimum ratio over the workgroups' partials (primal_solvers.py:166, np.argmin)
-    VI best{LPX_INF, LPX_NOIDX};
-    int64_t bk = -1;
-    double dmax = -LPX_INF;
+    // leaving row: first minimum ratio over the workgroups' partials (primal_solvers.py:166, np.argmin), each with its payload
+    TbRatio best{LPX_INF, LPX_NOIDX, -LPX_INF, 0.0, 0.0, -1};
     for (int64_t k = tid; k < a.nratio; k += TB_THREADS) {
-        const double v = a.ratio.v0[k];
-        const int64_t r = a.ratio.i0[k];
-        if (vi_less(v, r, best.v, best.i)) { best = VI{v, r}; bk = k; }
-        dmax = fmax(dmax, a.ratio.v1[k]);
+        const TbRatio t{a.ratio.v0[k], a.ratio.i0[k], a.ratio.v1[k], a.b.dbest[k], a.b.xbest[k], a.ratio.i1[k]};
+        const double dm = fmax(best.dmax, t.dmax);
+        if (vi_less(t.th, t.row, best.th, best.row)) best = t;
+        best.dmax = dm;
     }
     LPX_TB_STAMP(1, 2);
-    const VI w = block_argmin(best, red);
-    dmax = block_max(dmax, red);
+    const TbRatio w = tb_ratio_reduce(best, sh_ratio);
     LPX_TB_STAMP(1, 3);
+    const double dmax = w.dmax;
     if (dmax <= 0.0) { // primal_solvers.py:144-147
         if (g == 0) {
             ctrl->aux_val = dmax;
@@ -317,14 +335,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         }
         return;
     }
-    if (bk >= 0 && best.i == w.i) { // rows are distinct: one thread
-        sh_pay[0] = a.b.dbest[bk];
-        sh_pay[1] = a.b.xbest[bk];
-        sh_bv = a.ratio.i1[bk];
-    }
-    __syncthreads();
-    const int64_t r = w.i, leaving = sh_bv;
-    const double dr = sh_pay[0], xr = sh_pay[1];
+    const int64_t r = w.row, leaving = w.bv;
+    const double dr = w.dv, xr = w.xv;
     const bool cond = s.slot_var != nullptr;
     LPX_TB_STAMP(1, 4);
     // eta column (primal_solvers.py:217-245), x_B (:251-253)
@@ -341,10 +353,14 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         const double erv = (l32 < P) ? a.b.E[r * TB_KMAX + l32] : 0.0;
         rowp = incol ? s.T[r * s.ld + g] : 0.0;
 #pragma unroll
-        for (int u = 0; u < TB_KMAX; ++u)
-            if (u < P)
-                rowp = tb_apply(rowp, (int)g == __builtin_amdgcn_readlane(sv, u), (int)r == __builtin_amdgcn_readlane(pv, u),
-                                tf_readlane_f64(erv, u), ru[u], cond);
+        for (int u = 0; u < TB_KMAX; ++u) {
+            if (u < P) {
+                const double er = tf_readlane_f64(erv, u);
+                const bool isr = (int)r == __builtin_amdgcn_readlane(pv, u); // wave-uniform
+                const double v = isr ? er * ru[u] : fma(er, ru[u], rowp);
+                rowp = ((int)g == __builtin_amdgcn_readlane(sv, u)) ? (cond ? er : (isr ? 1.0 : 0.0)) : v;
+            }
+        }
         if (incol) a.b.R[P * a.b.ldr + g] = rowp;
     }
     LPX_TB_STAMP(1, 6);
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
             a.b.rc[g] = rc;
             tb_price_one(s.pricing, rc, v, g, c);
         }
-        c = tb_price_reduce(s.pricing, c, red, &sh_slot);
+        c = tb_price_reduce(s.pricing, c, sh_price);
         if (tid == 0) {
             a.price.v0[blockIdx.x] = c.mn;
             a.price.i0[blockIdx.x] = c.var;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         ctrl->pivots += 1;
         ctrl->leave_r = r;
         ctrl->leave_var = leaving;
-        ctrl->ratio_val = w.v;
+        ctrl->ratio_val = w.th;
         ctrl->aux_val = dmax;
         ctrl->flip = 0;
         ctrl->f32_phase = 0;
