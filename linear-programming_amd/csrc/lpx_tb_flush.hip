@@ -1,5 +1,8 @@
-// lpx_tb_flush.hip -- instantiations of the deferred-update pass (lpx_tb_flush.hpp) and their launcher
+// lpx_tb_flush.hip -- the deferred-update pass (lpx_tb_flush.hpp): launcher and the instantiations for blocks of 8 and 16
+// (blocks of 32 are compiled in lpx_tb_flush32.hip: the unrolled chains dominate the build time, two files build in parallel)
 #include "lpx_tb_flush.hpp"
+
+void lpx_tb_flush_launch32(const TbFlushArgs &f, int nt, dim3 grid, hipStream_t st);
 
 template <int KB>
 static void tb_launch_flush(const TbFlushArgs &f, int nt, dim3 grid, hipStream_t st)
@@ -14,5 +17,5 @@ void lpx_tb_flush_launch(const TbFlushArgs &f, int kb, int nt, void *stream)
     hipStream_t st = (hipStream_t)stream;
     if (kb == 8) tb_launch_flush<8>(f, nt, grid, st);
     else if (kb == 16) tb_launch_flush<16>(f, nt, grid, st);
-    else tb_launch_flush<32>(f, nt, grid, st);
+    else lpx_tb_flush_launch32(f, nt, grid, st);
 }
