@@ -1988,6 +1988,39 @@ static int tableau_dual_iterate_fused(const lpx_tableau *s, const TabWs &w, int6
     return LPX_OK;
 }
 
+static int tableau_dual_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
+{
+    const TbArgs a = tb_args(s, w);
+    const int64_t ncopy = lpx_roundup(s->n + 1, 2);
+    const int64_t nrow = lpx_cdiv(ncopy > s->m + 1 ? ncopy : s->m + 1, TB_THREADS);
+    const int64_t ncol = lpx_cdiv(s->n > s->m + 1 ? s->n : s->m + 1, TB_THREADS);
+    hipLaunchKernelGGL(k_tbd_boot, dim3((unsigned)ncol), dim3(TB_THREADS), 0, st, a);
+    int64_t it = 0;
+    auto one = [&](hipStream_t q) {
+        TbArgs b = a;
+        b.u = (int)(it % KB);
+        hipLaunchKernelGGL(k_tbd_row, dim3((unsigned)nrow), dim3(TB_THREADS), 0, q, b);
+        hipLaunchKernelGGL(k_tbd_column, dim3((unsigned)ncol), dim3(TB_THREADS), 0, q, b);
+        it += 1;
+    };
+    struct {
+        lpx_tableau s;
+        int kb, what;
+    } key;
+    memset(&key, 0, sizeof key);
+    key.s = *s; key.kb = KB; key.what = 6;
+    while (iters > 0) { // a block = KB pivots' decisions (replayed as one graph) + one pass over the tableau
+        const int64_t k = iters < KB ? iters : KB;
+        it = 0;
+        const int rc = lpx_run_iterations(&key, sizeof key, k, st, one, KB, true);
+        if (rc) return rc;
+        tb_flush(s, w, KB, st);
+        iters -= k;
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
     int rc = check_tableau(s);
@@ -1998,6 +2031,7 @@ extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, voi
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
     if (iters <= 0) return LPX_OK;
+    if (const int kb = t_block_size(s)) return tableau_dual_iterate_blocked(s, w, iters, st, kb);
     if (t_use_fused(s)) return tableau_dual_iterate_fused(s, w, iters, st);
     const lpx_tableau sv = *s;
     auto one = [&](hipStream_t q) {

@@ -421,3 +421,236 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The same chain for the DUAL rules (dual_solvers.py:47-108) -- the decisions come in the dual's order:
+//     k_tbd_row(P):    leaving row r = first x_B < 0 from the partials over xb[] (optimality: min x_B); row r of T0 with
+//                      the P pending updates applied -> R[P][.] (the dual row AND this update's old pivot row); ratio test
+//                      theta_j = (-rc_j) / row_j over row_j < 0 against rc[]: per-workgroup partials (first argmin by
+//                      variable id) that carry the winner's slot, reduced cost and row entry (the pivot element)
+//     k_tbd_column(P): entering variable from the partials, dual unboundedness (min(row) >= 0); column of T0 with the P
+//                      pending updates applied; eta column -> E[.][P]; xb[] and rc[] updated eagerly; partials over the
+//                      new xb[] for the next pivot; bookkeeping
+// and the same pass (k_tb_flush2) after a block.  As in the primal chain no launch reads a word it writes: x_B[r] comes
+// from R[P][n] (the row kernel formed it), the entering reduced cost and the pivot element ride in the partials.
+// ---------------------------------------------------------------------------------------------------------
+struct TbXb {
+    double mn;
+    int64_t first;
+};
+__device__ __forceinline__ TbXb tb_xb_reduce(TbXb t, TbXb *sh)
+{
+    return tb_block_reduce(t, [](TbXb x, TbXb y) { return TbXb{fmin(x.mn, y.mn), y.first < x.first ? y.first : x.first}; }, sh);
+}
+struct TbDual {
+    double th;
+    int64_t var, slot;
+    double rowmin, rcv, drv;
+};
+__device__ __forceinline__ TbDual tb_dual_reduce(TbDual t, TbDual *sh)
+{
+    return tb_block_reduce(t, [](TbDual x, TbDual y) {
+        TbDual u = vi_less(y.th, y.var, x.th, x.var) ? y : x;
+        u.rowmin = fmin(x.rowmin, y.rowmin);
+        return u;
+    }, sh);
+}
+
+// start of a call: rc[] and xb[] from the tableau, partials over x_B
+__global__ __launch_bounds__(TB_THREADS) void k_tbd_boot(TbArgs a)
+{
+    __shared__ TbXb sh_xb[TB_THREADS / 64];
+    const lpx_tableau &s = a.s;
+    const int64_t g = (int64_t)blockIdx.x * TB_THREADS + threadIdx.x;
+    if (g == 0) *a.b.cnt = 0;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    if (g < s.n) a.b.rc[g] = s.T[s.m * s.ld + g];
+    if ((int64_t)blockIdx.x >= a.nratio) return;
+    TbXb t{LPX_INF, LPX_NOIDX};
+    if (g < s.m) {
+        const double v = s.T[g * s.ld + s.n];
+        a.b.xb[g] = v;
+        t = TbXb{v, v < 0.0 ? g : LPX_NOIDX};
+    }
+    t = tb_xb_reduce(t, sh_xb);
+    if (threadIdx.x == 0) {
+        a.ratio.v0[blockIdx.x] = t.mn;
+        a.ratio.i0[blockIdx.x] = t.first;
+    }
+}
+
+__global__ __launch_bounds__(TB_THREADS) void k_tbd_row(TbArgs a)
+{
+    __shared__ TbXb sh_xb[TB_THREADS / 64];
+    __shared__ TbDual sh_du[TB_THREADS / 64];
+    const lpx_tableau &s = a.s;
+    lpx_ctrl *ctrl = s.ctrl;
+    const int tid = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * TB_THREADS + tid;
+    const int P = a.u;
+    const int64_t m = s.m, n = s.n, ncopy = lpx_roundup_dev(n + 1, 2);
+    if (P == 0) { // a new block: nothing pending (also after the loop has ended: the flush then applies nothing)
+        if (g <= m) a.b.rowflag[g] = 0u;
+        if (g == 0) *a.b.cnt = 0;
+    }
+    // loads whose addresses depend on nothing decided in this launch
+    const int32_t status = ctrl->status;
+    const bool f32 = ctrl->f32_phase != 0;
+    const bool incol = g < ncopy, cond = s.slot_var != nullptr;
+    double ru[TB_KMAX];
+#pragma unroll
+    for (int u = 0; u < TB_KMAX; ++u) ru[u] = (u < P && incol) ? a.b.R[u * a.b.ldr + g] : 0.0;
+    const double rcg = (g < n) ? a.b.rc[g] : 0.0;
+    const int64_t varg = (g < n) ? t_var(s, g) : LPX_NOIDX;
+    const bool basic = (g < n && !cond) ? s.var_state[g] == LPX_VS_BASIC : false; // dual_solvers.py:38-39
+    const int l32 = tid & 31;
+    const int pv = (l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2;
+    const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
+    if (status != LPX_RUNNING) return;
+    // leaving row: first x_B < 0 (dual_solvers.py:47-54)
+    TbXb xp{LPX_INF, LPX_NOIDX};
+    for (int64_t k = tid; k < a.nratio; k += TB_THREADS) {
+        xp.mn = fmin(xp.mn, a.ratio.v0[k]);
+        const int64_t f = a.ratio.i0[k];
+        xp.first = f < xp.first ? f : xp.first;
+    }
+    xp = tb_xb_reduce(xp, sh_xb);
+    const bool opt = lpx_is_optimal_min(xp.mn);
+    const int64_t r = xp.first;
+    if (g == 0) {
+        ctrl->counter += 1;
+        ctrl->price_val = xp.mn;
+        if (opt) ctrl->status = LPX_OPTIMAL;
+        else ctrl->leave_r = r;
+    }
+    if (opt) return;
+    // row r of the tableau as the P pending updates leave it
+    double rowp;
+    {
+        const double erv = (l32 < P) ? a.b.E[r * TB_KMAX + l32] : 0.0;
+        rowp = incol ? s.T[r * s.ld + g] : 0.0;
+#pragma unroll
+        for (int u = 0; u < TB_KMAX; ++u) {
+            if (u < P) {
+                const double er = tf_readlane_f64(erv, u);
+                const bool isr = (int)r == __builtin_amdgcn_readlane(pv, u); // wave-uniform
+                const double v = isr ? er * ru[u] : fma(er, ru[u], rowp);
+                rowp = ((int)g == __builtin_amdgcn_readlane(sv, u)) ? (cond ? er : (isr ? 1.0 : 0.0)) : v;
+            }
+        }
+        if (incol) a.b.R[P * a.b.ldr + g] = rowp;
+    }
+    // ratio test over the columns (dual_solvers.py:61-80, utils.py:12-17)
+    if ((int64_t)blockIdx.x < a.nprice) {
+        TbDual c{LPX_INF, LPX_NOIDX, -1, LPX_INF, 0.0, 0.0};
+        if (g < n) {
+            const double row = basic ? 0.0 : rowp;
+            c = TbDual{lpx_dsd(rcg, row, f32), varg, g, row, rcg, rowp};
+        }
+        c = tb_dual_reduce(c, sh_du);
+        if (tid == 0) {
+            a.price.v0[blockIdx.x] = c.th;
+            a.price.i0[blockIdx.x] = c.var;
+            a.price.i1[blockIdx.x] = c.slot;
+            a.price.v1[blockIdx.x] = c.rowmin;
+            a.b.dbest[blockIdx.x] = c.drv;
+            a.b.xbest[blockIdx.x] = c.rcv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB_THREADS) void k_tbd_column(TbArgs a)
+{
+    __shared__ TbXb sh_xb[TB_THREADS / 64];
+    __shared__ TbDual sh_du[TB_THREADS / 64];
+    const lpx_tableau &s = a.s;
+    lpx_ctrl *ctrl = s.ctrl;
+    const int tid = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * TB_THREADS + tid;
+    const int P = a.u;
+    const int64_t m = s.m, n = s.n;
+    // loads whose addresses depend on nothing decided in this launch
+    const int32_t status = ctrl->status;
+    const int64_t r = ctrl->leave_r;
+    const bool inm = g <= m, cond = s.slot_var != nullptr;
+    double e[TB_KMAX];
+    {
+        const double *Eti = a.b.Et + (inm ? g : 0);
+#pragma unroll
+        for (int u = 0; u < TB_KMAX; ++u) e[u] = (u < P) ? Eti[u * a.b.lde] : 0.0;
+    }
+    const double xg = (g < m) ? a.b.xb[g] : 0.0;
+    const double rcg = (g < n) ? a.b.rc[g] : 0.0;
+    const double rpg = (g < n) ? a.b.R[P * a.b.ldr + g] : 0.0; // row r as the pending updates leave it (k_tbd_row)
+    const double xr = a.b.R[P * a.b.ldr + n];                  // its x_B entry: x_B[r] before this pivot
+    const int l32 = tid & 31;
+    const int pv = (l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2;
+    const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
+    if (status != LPX_RUNNING) return;
+    // entering variable: first argmin of theta by variable id; dual unboundedness (dual_solvers.py:41-44, :56-59)
+    TbDual best{LPX_INF, LPX_NOIDX, -1, LPX_INF, 0.0, 0.0};
+    for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
+        const TbDual t{a.price.v0[k], a.price.i0[k], a.price.i1[k], a.price.v1[k], a.b.xbest[k], a.b.dbest[k]};
+        const double rm = fmin(best.rowmin, t.rowmin);
+        if (vi_less(t.th, t.var, best.th, best.var)) best = t;
+        best.rowmin = rm;
+    }
+    const TbDual w = tb_dual_reduce(best, sh_du);
+    if (w.rowmin >= 0.0) {
+        if (g == 0) {
+            ctrl->aux_val = w.rowmin;
+            ctrl->status = LPX_DUAL_UNBOUNDED;
+        }
+        return;
+    }
+    const int64_t j = w.var, slot = w.slot;
+    const double dr = w.drv, rcv = w.rcv;
+    // the entering column as the pending updates leave it; eta column (primal_solvers.py:217-245); x_B (:251-253)
+    const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
+    double di = inm ? s.T[g * s.ld + slot] : 0.0;
+    di = tb_column_chain(di, P, (int)slot, (int)g, sv, pv, e, rv, cond);
+    double nx = LPX_INF;
+    if (inm) {
+        a.d[g] = di;
+        const double eg = (g == r) ? 1.0 / dr : (-di) / dr; // e[m] eliminates rc_j
+        a.b.E[g * TB_KMAX + P] = eg;
+        a.b.Et[P * a.b.lde + g] = eg;
+        if (g < m) {
+            nx = (g == r) ? eg * xr : fma(eg, xr, xg);
+            a.b.xb[g] = nx;
+        }
+    }
+    if ((int64_t)blockIdx.x < a.nratio) { // partials over the new x_B: the next pivot's leaving row
+        TbXb t{nx, (g < m && nx < 0.0) ? g : LPX_NOIDX};
+        t = tb_xb_reduce(t, sh_xb);
+        if (tid == 0) {
+            a.ratio.v0[blockIdx.x] = t.mn;
+            a.ratio.i0[blockIdx.x] = t.first;
+        }
+    }
+    if (g < n) { // the reduced-cost row after this pivot
+        const double em = (-rcv) / dr;
+        a.b.rc[g] = (g == slot) ? (cond ? em : 0.0) : fma(em, rpg, rcg);
+    }
+    if (g == 0) { // bookkeeping (td_finish)
+        const int64_t leaving = s.basis[r];
+        s.basis[r] = j;
+        t_swap_columns(s, j, leaving);
+        if (s.log && ctrl->pivots < s.log_cap) {
+            s.log[3 * ctrl->pivots + 0] = r;
+            s.log[3 * ctrl->pivots + 1] = j;
+            s.log[3 * ctrl->pivots + 2] = leaving;
+        }
+        ctrl->pivots += 1;
+        ctrl->enter_j = j;
+        ctrl->leave_var = leaving;
+        ctrl->ratio_val = w.th;
+        ctrl->aux_val = w.rowmin;
+        ctrl->flip = 0;
+        ctrl->f32_phase = 0;
+        a.b.prow[P] = r;
+        a.b.pslot[P] = slot;
+        a.b.rowflag[r] |= 1u << P;
+        *a.b.cnt = P + 1;
+    }
+}

@@ -249,7 +249,7 @@ def test_tableau_dantzig_opt_in_matches_oracle(m, n, seed):
 DUAL_CASES = [c for c in load("random.json") + load("textbook.json") + load("random_xlarge.json") if c["solver"].startswith("Dual")]
 
 
-@pytest.mark.parametrize("chain", ["one-launch", "four-launch"])
+@pytest.mark.parametrize("chain", ["one-launch", "four-launch", "deferred"])
 @pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
 @pytest.mark.parametrize("cs", DUAL_CASES, ids=case_id)
 def test_dual_tableau_matches_reference(cs, condensed, chain, monkeypatch):
@@ -262,6 +262,9 @@ def test_dual_tableau_matches_reference(cs, condensed, chain, monkeypatch):
 
     if chain == "four-launch":
         monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+    if chain == "deferred":  # blocks of 8 pivots decided from the stale tableau, one pass applies them (k_tbd_row / _column)
+        monkeypatch.setenv("LPX_TABLEAU_BLOCK", "8")
+        monkeypatch.setenv("LPX_TABLEAU_BLOCK_MIN_MB", "0")
     ref = cs["ref"]
     c, A, b, basis = problem_of(cs)
     if ref["exception"] == "BasisIsDualInfeasibleError":
@@ -295,7 +298,7 @@ def test_dual_tableau_matches_reference(cs, condensed, chain, monkeypatch):
         assert abs(res.cost - ro.cost) <= 1e-13 * max(1.0, abs(ro.cost))
 
 
-@pytest.mark.parametrize("rows", ["0", "1", "4"])
+@pytest.mark.parametrize("rows", ["0", "1", "4", "deferred8", "deferred16", "deferred32"])
 @pytest.mark.parametrize("m,n,condensed", [(300, 700, True), (300, 700, False), (530, 1061, True), (64, 1200, True),
                                            (700, 760, True)])
 def test_dual_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, monkeypatch):
@@ -306,7 +309,11 @@ def test_dual_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, 
     from linprog_amd.tableau import DualTableauSimplexSolver
     from oracle import oracle as O
 
-    monkeypatch.setenv("LPX_FUSED_ROWS", rows)
+    if rows.startswith("deferred"):  # the deferred-update chain of the dual rules, calls ending anywhere in a block
+        monkeypatch.setenv("LPX_TABLEAU_BLOCK", rows[8:])
+        monkeypatch.setenv("LPX_TABLEAU_BLOCK_MIN_MB", "0")
+    else:
+        monkeypatch.setenv("LPX_FUSED_ROWS", rows)
     c, A, b, basis = gen.gen_dual(m, n, 5)
     s = logged(DualTableauSimplexSolver, 4096)(c, A, b, basis, condensed=condensed)
     assert s._engine.T_alt is not None
