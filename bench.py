@@ -435,7 +435,8 @@ def bench_dual(args):
     dt_t, k1_t = run(tab, lambda eng, k: eng.enqueue(k))
     log_t = tab.pivot_log()
     ncarry = tab._engine.n
-    one_launch = tab._engine.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
+    kb = int(lib.lpx_tableau_block_size(C.byref(tab._engine.s)))  # deferred updates: pivots per pass over the tableau
+    one_launch = kb == 0 and tab._engine.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
     del tab
     torch.cuda.empty_cache()
     Rev = type("BenchDualRevised", (DualRevisedSimplexSolver,), {"_LOG_CAP": W + 2 * K + 8})
@@ -464,10 +465,12 @@ def bench_dual(args):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"gen_dual(m={m}, n={n}, seed={args.seed}) DualTableauSimplexSolver loop (condensed tableau, "
                                   f"{m + 1} x {ncarry + 1})", "m": m, "n": n,
-                      "launches_per_pivot": 1 if one_launch else 4,
+                      "launches_per_pivot": (2 + 1.0 / kb) if kb else (1 if one_launch else 4),
+                      "pivots_per_pass_over_the_tableau": kb if kb else 1,
                       "revised_form_pivots_per_s": K / dt_r, "revised_form_k1_ms": k1_r * 1e3},
-           "roofline": {"bound": "hbm", "kernel": "k_td_fused (update + next pivot's leaving row / ratio test / column, two "
-                                                  "buffers)" if one_launch else "k_rank1<tableau>", "achieved": bytes_t / k1_t / 1e9, "peak": HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "kernel": "k_tb_flush2 (the pass that applies a block of pending rank-1 updates)" if kb
+                        else "k_td_fused (update + next pivot's leaving row / ratio test / column, two "
+                             "buffers)" if one_launch else "k_rank1<tableau>", "achieved": bytes_t / k1_t / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": bytes_t / k1_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "bytes_per_launch": bytes_t, "avg_launch_ms": k1_t * 1e3},
            "cpu_baseline": cpu}
