@@ -303,10 +303,14 @@ class TableauEngine:
         left = int(maxiters)
         ctrl = None
         first = True
+        # deferred updates (large tableaus): whole blocks between two looks at the control block, and more of them --
+        # every call starts by re-reading the reduced-cost row and x_B from T and ends with a pass over T
+        kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
+        chunk, first_chunk = (8 * kb, kb) if kb > 0 else (self.CHUNK, self.FIRST_CHUNK)
         while left > 0:
             # short first chunk (eager launches): small solves end here; later chunks are long enough for
             # liblpx to replay them as hipGraphs
-            k = min(left, self.FIRST_CHUNK if first else self.CHUNK)
+            k = min(left, first_chunk if first else chunk)
             first = False
             self.enqueue(k)
             left -= k
