@@ -288,6 +288,12 @@ int lpx_tableau_block_begin(const lpx_tableau *s, void *stream);
 int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream);
 int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream);
 int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void *stream);
+/* The same for the dual rules (dual_solvers.py:47-108; message layout of lpx_tableau_dual_propose): every rank picks the
+ * leaving row from its replica of x_B, proposes (theta, variable, column as the pending updates leave it); the commit takes
+ * the first argmin of theta over the ranks.  Flush with lpx_tableau_block_flush. */
+int lpx_tableau_dual_block_begin(const lpx_tableau *s, void *stream);
+int lpx_tableau_dual_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream);
+int lpx_tableau_dual_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream);
 /* x[n_global-sized on rank owning..] : x_B and basis are replicated, so every rank can expand: x, cost. */
 int lpx_tableau_expand(const lpx_tableau *s, const float *c_global, double *x, double *cost, void *stream);
 

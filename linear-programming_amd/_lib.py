@@ -95,6 +95,9 @@ _SIGS = {
     "lpx_tableau_block_propose": (C.c_int, [C.POINTER(LpxTableau), i64, vp, vp]),
     "lpx_tableau_block_commit": (C.c_int, [C.POINTER(LpxTableau), i64, vp, i64, vp]),
     "lpx_tableau_block_flush": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
+    "lpx_tableau_dual_block_begin": (C.c_int, [C.POINTER(LpxTableau), vp]),
+    "lpx_tableau_dual_block_propose": (C.c_int, [C.POINTER(LpxTableau), i64, vp, vp]),
+    "lpx_tableau_dual_block_commit": (C.c_int, [C.POINTER(LpxTableau), i64, vp, i64, vp]),
     "lpx_refine_workspace_bytes": (i64, [i64]),
     "lpx_revised_refine": (C.c_int, [C.POINTER(LpxRevised), i64, C.c_int, vp, i64, vp, vp]),
     "lpx_invert_workspace_bytes": (i64, [i64]),

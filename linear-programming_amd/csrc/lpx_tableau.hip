@@ -2000,7 +2000,7 @@ static int tableau_dual_iterate_blocked(const lpx_tableau *s, const TabWs &w, in
         TbArgs b = a;
         b.u = (int)(it % KB);
         hipLaunchKernelGGL(k_tbd_row, dim3((unsigned)nrow), dim3(TB_THREADS), 0, q, b);
-        hipLaunchKernelGGL(k_tbd_column, dim3((unsigned)ncol), dim3(TB_THREADS), 0, q, b);
+        hipLaunchKernelGGL((k_tbd_column<TB_LOCAL>), dim3((unsigned)ncol), dim3(TB_THREADS), 0, q, b);
         it += 1;
     };
     struct {
@@ -2017,6 +2017,53 @@ static int tableau_dual_iterate_blocked(const lpx_tableau *s, const TabWs &w, in
         tb_flush(s, w, KB, st);
         iters -= k;
     }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---- column-partitioned dual loop with deferred updates (see lpx_tableau_block_* for the primal twin): the leaving row
+// comes from the replicated x_B, so every rank picks it without communication; each rank proposes its best column
+extern "C" int lpx_tableau_dual_block_begin(const lpx_tableau *s, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    const TbArgs a = tb_args(s, w);
+    hipLaunchKernelGGL(k_tbd_boot, dim3((unsigned)lpx_cdiv(s->n > s->m + 1 ? s->n : s->m + 1, TB_THREADS)), dim3(TB_THREADS), 0,
+                       (hipStream_t)stream, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_dual_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    TbArgs a = tb_args(s, w);
+    a.u = (int)pending;
+    a.sendbuf = sendbuf;
+    const int64_t ncopy = lpx_roundup(s->n + 1, 2);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_tbd_row, dim3((unsigned)lpx_cdiv(ncopy > s->m + 1 ? ncopy : s->m + 1, TB_THREADS)), dim3(TB_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_tbd_column<TB_PROPOSE>), dim3((unsigned)lpx_cdiv(s->m + 1, TB_THREADS)), dim3(TB_THREADS), 0, st, a);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+extern "C" int lpx_tableau_dual_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream)
+{
+    int rc = check_tableau(s);
+    if (rc) return rc;
+    LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
+    LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
+    const TabWs w = tab_ws(s->m, s->n, s->workspace);
+    TbArgs a = tb_args(s, w);
+    a.u = (int)pending;
+    a.recv = recvbuf;
+    a.nranks = nranks;
+    a.msg = lpx_tableau_msg_len(s->m);
+    hipLaunchKernelGGL((k_tbd_column<TB_SELECT>), dim3((unsigned)lpx_cdiv(s->n > s->m + 1 ? s->n : s->m + 1, TB_THREADS)),
+                       dim3(TB_THREADS), 0, (hipStream_t)stream, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }

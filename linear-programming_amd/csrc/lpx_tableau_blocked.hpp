@@ -559,6 +559,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tbd_row(TbArgs a)
     }
 }
 
+// MODE as for k_tb_column: TB_LOCAL (unpartitioned), TB_PROPOSE (this rank's best column -> sendbuf: [theta, variable,
+// column]), TB_SELECT (first argmin of theta over the ranks' proposals -- lowest variable id on ties, np.argmin's first
+// minimum whichever rank holds it; no candidate anywhere is exactly min(row) >= 0 -- then the column from the winner's message)
+template <int MODE>
 __global__ __launch_bounds__(TB_THREADS) void k_tbd_column(TbArgs a)
 {
     __shared__ TbXb sh_xb[TB_THREADS / 64];
@@ -588,27 +592,62 @@ __global__ __launch_bounds__(TB_THREADS) void k_tbd_column(TbArgs a)
     const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
     if (status != LPX_RUNNING) return;
     // entering variable: first argmin of theta by variable id; dual unboundedness (dual_solvers.py:41-44, :56-59)
-    TbDual best{LPX_INF, LPX_NOIDX, -1, LPX_INF, 0.0, 0.0};
-    for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
-        const TbDual t{a.price.v0[k], a.price.i0[k], a.price.i1[k], a.price.v1[k], a.b.xbest[k], a.b.dbest[k]};
-        const double rm = fmin(best.rowmin, t.rowmin);
-        if (vi_less(t.th, t.var, best.th, best.var)) best = t;
-        best.rowmin = rm;
-    }
-    const TbDual w = tb_dual_reduce(best, sh_du);
-    if (w.rowmin >= 0.0) {
-        if (g == 0) {
-            ctrl->aux_val = w.rowmin;
-            ctrl->status = LPX_DUAL_UNBOUNDED;
+    TbDual w{LPX_INF, LPX_NOIDX, -1, LPX_INF, 0.0, 0.0};
+    int64_t win = 0;
+    if (MODE == TB_SELECT) {
+        for (int64_t q = 0; q < a.nranks; ++q) { // a handful of ranks: every thread scans them
+            const double v = a.recv[q * a.msg];
+            const int64_t idx = (int64_t)a.recv[q * a.msg + 1];
+            if (vi_less(v, idx, w.th, w.var)) { w.th = v; w.var = idx; win = q; }
         }
-        return;
+        if (w.th == LPX_INF) {
+            if (g == 0) {
+                ctrl->aux_val = 0.0;
+                ctrl->status = LPX_DUAL_UNBOUNDED;
+            }
+            return;
+        }
+        const double *col = a.recv + win * a.msg + 2;
+        w.slot = t_slot(s, w.var); // -1: the column lives on another rank
+        w.drv = col[r];
+        w.rcv = col[m];
+        w.rowmin = -1.0;
+    } else {
+        TbDual best{LPX_INF, LPX_NOIDX, -1, LPX_INF, 0.0, 0.0};
+        for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
+            const TbDual t{a.price.v0[k], a.price.i0[k], a.price.i1[k], a.price.v1[k], a.b.xbest[k], a.b.dbest[k]};
+            const double rm = fmin(best.rowmin, t.rowmin);
+            if (vi_less(t.th, t.var, best.th, best.var)) best = t;
+            best.rowmin = rm;
+        }
+        w = tb_dual_reduce(best, sh_du);
+        if (MODE == TB_LOCAL && w.rowmin >= 0.0) {
+            if (g == 0) {
+                ctrl->aux_val = w.rowmin;
+                ctrl->status = LPX_DUAL_UNBOUNDED;
+            }
+            return;
+        }
     }
     const int64_t j = w.var, slot = w.slot;
     const double dr = w.drv, rcv = w.rcv;
     // the entering column as the pending updates leave it; eta column (primal_solvers.py:217-245); x_B (:251-253)
-    const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
-    double di = inm ? s.T[g * s.ld + slot] : 0.0;
-    di = tb_column_chain(di, P, (int)slot, (int)g, sv, pv, e, rv, cond);
+    double di;
+    if (MODE == TB_SELECT) {
+        di = inm ? a.recv[win * a.msg + 2 + g] : 0.0;
+    } else {
+        const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
+        di = inm ? s.T[g * s.ld + slot] : 0.0;
+        di = tb_column_chain(di, P, (int)slot, (int)g, sv, pv, e, rv, cond);
+    }
+    if (MODE == TB_PROPOSE) {
+        if (g == 0) {
+            a.sendbuf[0] = w.th;
+            a.sendbuf[1] = (double)j; // exact: ids < 2^53
+        }
+        if (inm) a.sendbuf[2 + g] = di;
+        return;
+    }
     double nx = LPX_INF;
     if (inm) {
         a.d[g] = di;

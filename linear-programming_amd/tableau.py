@@ -236,6 +236,17 @@ class TableauEngine:
         ex = self.exchange
         iters = int(iters)
         if self.dual:
+            kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
+            if kb > 0 and iters > 0:  # large slices: deferred updates (lpx.h, lpx_tableau_dual_block_*)
+                _lib.check(self.lib.lpx_tableau_dual_block_begin(C.byref(self.s), st))
+                for it in range(iters):
+                    u = it % kb
+                    _lib.check(self.lib.lpx_tableau_dual_block_propose(C.byref(self.s), u, ex.sendbuf.data_ptr(), st))
+                    ex.all_gather()
+                    _lib.check(self.lib.lpx_tableau_dual_block_commit(C.byref(self.s), u, ex.recvbuf.data_ptr(), self.nranks, st))
+                    if u == kb - 1 or it + 1 == iters:
+                        _lib.check(self.lib.lpx_tableau_block_flush(C.byref(self.s), kb, st))
+                return
             if not self.LOOKAHEAD:
                 for it in range(iters):
                     _lib.check(self.lib.lpx_tableau_dual_propose(C.byref(self.s), ex.sendbuf.data_ptr(), st))

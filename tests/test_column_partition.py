@@ -91,3 +91,15 @@ def test_dual_product_path_lookahead_and_layouts(env):
     (lpx_tableau_dual_commit_begin) and gathers them while it runs; here the plain propose -> all-gather -> commit loop and
     the full (every column) layout, with and without lookahead.  All must give the oracle's pivot sequence."""
     _run("gpu-dual", 2, 64, 128, 2, 100000, **env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,m,n,env", [
+    (2, 64, 128, {"LPX_TABLEAU_BLOCK": "8"}), (3, 50, 121, {"LPX_TABLEAU_BLOCK": "32"}),
+    (2, 64, 128, {"LPX_TABLEAU_BLOCK": "16", "LPX_TABLEAU_CONDENSED": "0"}),
+    (3, 50, 121, {"LPX_TABLEAU_BLOCK": "8", "LPX_TABLEAU_CONDENSED": "0"})],
+    ids=lambda v: ",".join(f"{k[12:]}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_dual_product_path_deferred_updates(nproc, m, n, env):
+    """The column-partitioned DUAL loop with deferred updates (lpx_tableau_dual_block_*), forced on at test sizes, both
+    layouts: the oracle's pivot sequences."""
+    _run("gpu-dual", nproc, m, n, 2, 100000, LPX_TABLEAU_BLOCK_MIN_MB="0", **env)
