@@ -293,7 +293,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     elif rank == 0:
         # N>1: rank 0 regenerates the whole matrix and checks the partitioned run's first pivots against the oracle
         full = problems.gen_primal_columns(m, n, args.seed, 0, n)
-        kc = args.cpu_pivots if args.cpu_pivots is not None else (12 if m >= 10000 else 400)
+        kc = args.cpu_pivots if args.cpu_pivots is not None else (100 if m >= 10000 else 400)
         chk = cpu_baseline(args, m, n, full[0], full[1], full[2], full[3], solver, condensed, kc=kc)
         out["parity"] = None if chk is None else chk["parity"]
     del solver, eng

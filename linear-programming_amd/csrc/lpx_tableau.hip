@@ -1382,9 +1382,9 @@ static void tb_boot(const lpx_tableau *s, const TbArgs &a, hipStream_t st)
     const int64_t nboot = lpx_cdiv(s->n > s->m ? s->n : s->m, TB_THREADS);
     hipLaunchKernelGGL(k_tb_boot, dim3((unsigned)nboot), dim3(TB_THREADS), 0, st, a);
 }
-// the pass over the tableau: strips of 128 columns x bands of rows; a workgroup walks down its band 64 rows at a
-// time, so bands are whole multiples of 64 rows, and there are enough of them for ~2500 workgroups (measured on
-// the 20001 x 20001 tableau, tools/tb_flush_bench.hip: 1 / 4 / 16 / 32 / 63 bands -> 1.58 / 1.35 / 1.22 / 1.25 / 1.32 ms)
+// the pass over the tableau: strips of 128 columns x bands of rows; a workgroup (4 waves) walks down its band 32 rows at a
+// time, so bands are whole multiples of 32 rows, and there are enough of them for ~5000 workgroups (measured on the
+// 20001 x 20001 tableau, tools/tb_flush_bench.hip: bands of 2501 / 1251 / 640 / 320 rows -> 1.21 / 1.18 / 1.17 / 1.17 ms)
 static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q)
 {
     TbFlushArgs f{};
@@ -1393,9 +1393,9 @@ static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q
     const int64_t nstrips = lpx_cdiv(f.cols, TB2_COLS);
     int64_t rpb = lpx_env_int("LPX_TB_ROWS", 0);
     if (rpb <= 0) {
-        int64_t nbands = lpx_cdiv(2560, nstrips);
+        int64_t nbands = lpx_cdiv(5120, nstrips);
         if (nbands < 1) nbands = 1;
-        rpb = lpx_roundup(lpx_cdiv(f.rows, nbands), 64);
+        rpb = lpx_roundup(lpx_cdiv(f.rows, nbands), 32);
     }
     f.rpb = rpb;
     const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;

@@ -4,7 +4,7 @@
 // (8 cnt (rows + cols), re-read from L2 by every workgroup that needs them); fma per element: cnt.
 //
 // Mapping.  A workgroup owns ONE narrow strip (128 columns: one wave-width of column pairs) of a band of rows and walks
-// down it; its 8 waves take turns on groups of RG rows.  The strip's entries of the cnt pivot rows live in LDS
+// down it; its 4 waves take turns on groups of RG rows.  The strip's entries of the cnt pivot rows live in LDS
 // (cnt x 1 KiB), read once per group (one ds_read_b128 per update feeds 2 RG fma), so a wave's registers hold only data
 // in flight: RG rows of the tableau and their multipliers.  The multipliers e_u[i] of a row are the same for every lane:
 // each lane loads the one with its index modulo 16 (per group of 16 updates) and the fma takes it from there through a
@@ -95,7 +95,7 @@ struct Tb2Chain<KB, RG, FULL, KB> {
                                                 const uint32_t (&)[RG], uint32_t, uint32_t, bool) {}
 };
 
-template <int KB, int NT, int RG, bool FULL>
+template <int KB, int NT, int RG, bool FULL, int THREADS>
 __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2_t *prs, uint32_t fm0, uint32_t fm1, uint32_t fxmask,
                                          int64_t col, bool live, int64_t row0, int64_t row1)
 {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
     const int wave = threadIdx.x >> 6;
     const double *__restrict__ El = a.E + (threadIdx.x & 15);
     const uint32_t *__restrict__ rowflag = a.rowflag;
-    for (int64_t i0 = row0 + wave * RG; i0 < row1; i0 += TB2_WAVES * RG) {
+    for (int64_t i0 = row0 + wave * RG; i0 < row1; i0 += (THREADS / 64) * RG) {
         double x[RG][2], eg[RG][NG];
         uint32_t rf[RG];
         double *p = a.T + i0 * ld + col;
@@ -140,8 +140,8 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
 }
 
 // grid (strips of TB2_COLS columns, bands of rpb rows)
-template <int KB, int NT, int RG>
-__global__ __launch_bounds__(TB2_THREADS) void k_tb_flush2(TbFlushArgs a)
+template <int KB, int NT, int RG, int THREADS = TB2_THREADS>
+__global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
 {
     __shared__ d2_t prs_all[KB * 64];
     const int cnt = (int)*a.cnt;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TB2_THREADS) void k_tb_flush2(TbFlushArgs a)
     // work on column 0's data and store nothing
     const bool live = col_own < a.cols;
     const int64_t col = live ? col_own : 0;
-    for (int idx = threadIdx.x; idx < KB * 64; idx += TB2_THREADS) {
+    for (int idx = threadIdx.x; idx < KB * 64; idx += THREADS) {
         const int u = idx >> 6;
         const int64_t c = col0 + 2 * (idx & 63);
         d2_t v = (u < cnt && c < a.cols) ? *(const d2_t *)(a.R + u * a.ldr + c) : d2_t{0.0, 0.0};
@@ -177,6 +177,6 @@ __global__ __launch_bounds__(TB2_THREADS) void k_tb_flush2(TbFlushArgs a)
     const int64_t row0 = (int64_t)blockIdx.y * a.rpb;
     const int64_t row1 = (row0 + a.rpb < a.rows) ? row0 + a.rpb : a.rows;
     const d2_t *prs = prs_all + lane;
-    if (cnt == KB) tb2_walk<KB, NT, RG, true>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
-    else tb2_walk<KB, NT, RG, false>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
+    if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
+    else tb2_walk<KB, NT, RG, false, THREADS>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
 }
