@@ -46,58 +46,67 @@ __device__ __forceinline__ double tb_bcast(double e16)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// the chain of updates U .. KB-1 on a wave's group of RG rows; eg[q][g] = E[row q][16 g + lane % 16]
-template <int KB, int RG, bool FULL, int U>
+// the chain of updates U .. KB-1 on a wave's group of RG rows; eg[q][g] = E[row q][16 g + lane % 16]; a lane owns CV
+// column pairs, 128 columns apart (x[q][2 v], x[q][2 v + 1]; fm[c]: the updates that rewrite its column c)
+template <int KB, int RG, int CV, bool FULL, int U>
 struct Tb2Chain {
     // special: bit U set = this wave resets something before update U (a pivot row in the group, a rewritten column)
-    static __device__ __forceinline__ void fast(double (&x)[RG][2], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
-                                                uint32_t special, const uint32_t (&rf)[RG], uint32_t fm0, uint32_t fm1)
+    static __device__ __forceinline__ void fast(double (&x)[RG][2 * CV], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
+                                                uint32_t special, const uint32_t (&rf)[RG], const uint32_t (&fm)[2 * CV])
     {
         if (FULL || U < cnt) {
-            const d2_t pr = prs[U * 64];
+            d2_t pr[CV];
+#pragma unroll
+            for (int v = 0; v < CV; ++v) pr[v] = prs[(U * CV + v) * 64];
             if ((special >> U) & 1u) {
 #pragma unroll
                 for (int q = 0; q < RG; ++q) {
                     const bool row = (rf[q] >> U) & 1u;
-                    x[q][0] = (row || ((fm0 >> U) & 1u)) ? -0.0 : x[q][0];
-                    x[q][1] = (row || ((fm1 >> U) & 1u)) ? -0.0 : x[q][1];
+#pragma unroll
+                    for (int c = 0; c < 2 * CV; ++c) x[q][c] = (row || ((fm[c] >> U) & 1u)) ? -0.0 : x[q][c];
                 }
             }
 #pragma unroll
             for (int q = 0; q < RG; ++q) {
-                tb_fmac_bcast<U % 16>(x[q][0], eg[q][U / 16], pr[0]);
-                tb_fmac_bcast<U % 16>(x[q][1], eg[q][U / 16], pr[1]);
+#pragma unroll
+                for (int v = 0; v < CV; ++v) {
+                    tb_fmac_bcast<U % 16>(x[q][2 * v], eg[q][U / 16], pr[v][0]);
+                    tb_fmac_bcast<U % 16>(x[q][2 * v + 1], eg[q][U / 16], pr[v][1]);
+                }
             }
         }
-        Tb2Chain<KB, RG, FULL, U + 1>::fast(x, eg, prs, cnt, special, rf, fm0, fm1);
+        Tb2Chain<KB, RG, CV, FULL, U + 1>::fast(x, eg, prs, cnt, special, rf, fm);
     }
-    static __device__ __forceinline__ void slow(double (&x)[RG][2], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
-                                                const uint32_t (&rf)[RG], uint32_t fm0, uint32_t fm1, bool cond)
+    static __device__ __forceinline__ void slow(double (&x)[RG][2 * CV], const double (&eg)[RG][(KB + 15) / 16], const d2_t *prs, int cnt,
+                                                const uint32_t (&rf)[RG], const uint32_t (&fm)[2 * CV], bool cond)
     {
         if (FULL || U < cnt) {
-            const d2_t pr = prs[U * 64];
 #pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                const double e = tb_bcast<U % 16>(eg[q][U / 16]);
-                const bool isr = (rf[q] >> U) & 1u;
-                x[q][0] = tb_apply(x[q][0], (fm0 >> U) & 1u, isr, e, pr[0], cond);
-                x[q][1] = tb_apply(x[q][1], (fm1 >> U) & 1u, isr, e, pr[1], cond);
+            for (int v = 0; v < CV; ++v) {
+                const d2_t pr = prs[(U * CV + v) * 64];
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const double e = tb_bcast<U % 16>(eg[q][U / 16]);
+                    const bool isr = (rf[q] >> U) & 1u;
+                    x[q][2 * v] = tb_apply(x[q][2 * v], (fm[2 * v] >> U) & 1u, isr, e, pr[0], cond);
+                    x[q][2 * v + 1] = tb_apply(x[q][2 * v + 1], (fm[2 * v + 1] >> U) & 1u, isr, e, pr[1], cond);
+                }
             }
         }
-        Tb2Chain<KB, RG, FULL, U + 1>::slow(x, eg, prs, cnt, rf, fm0, fm1, cond);
+        Tb2Chain<KB, RG, CV, FULL, U + 1>::slow(x, eg, prs, cnt, rf, fm, cond);
     }
 };
-template <int KB, int RG, bool FULL>
-struct Tb2Chain<KB, RG, FULL, KB> {
-    static __device__ __forceinline__ void fast(double (&)[RG][2], const double (&)[RG][(KB + 15) / 16], const d2_t *, int, uint32_t,
-                                                const uint32_t (&)[RG], uint32_t, uint32_t) {}
-    static __device__ __forceinline__ void slow(double (&)[RG][2], const double (&)[RG][(KB + 15) / 16], const d2_t *, int,
-                                                const uint32_t (&)[RG], uint32_t, uint32_t, bool) {}
+template <int KB, int RG, int CV, bool FULL>
+struct Tb2Chain<KB, RG, CV, FULL, KB> {
+    static __device__ __forceinline__ void fast(double (&)[RG][2 * CV], const double (&)[RG][(KB + 15) / 16], const d2_t *, int, uint32_t,
+                                                const uint32_t (&)[RG], const uint32_t (&)[2 * CV]) {}
+    static __device__ __forceinline__ void slow(double (&)[RG][2 * CV], const double (&)[RG][(KB + 15) / 16], const d2_t *, int,
+                                                const uint32_t (&)[RG], const uint32_t (&)[2 * CV], bool) {}
 };
 
-template <int KB, int NT, int RG, bool FULL, int THREADS>
-__device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2_t *prs, uint32_t fm0, uint32_t fm1, uint32_t fxmask,
-                                         int64_t col, bool live, int64_t row0, int64_t row1)
+template <int KB, int NT, int RG, bool FULL, int THREADS, int CV>
+__device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2_t *prs, const uint32_t (&fm)[2 * CV], uint32_t fxmask,
+                                         const int64_t (&col)[CV], const bool (&live)[CV], int64_t row0, int64_t row1)
 {
     constexpr int NG = (KB + 15) / 16;
     const bool cond = a.cond != 0;
@@ -106,16 +115,18 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
     const double *__restrict__ El = a.E + (threadIdx.x & 15);
     const uint32_t *__restrict__ rowflag = a.rowflag;
     for (int64_t i0 = row0 + wave * RG; i0 < row1; i0 += (THREADS / 64) * RG) {
-        double x[RG][2], eg[RG][NG];
+        double x[RG][2 * CV], eg[RG][NG];
         uint32_t rf[RG];
-        double *p = a.T + i0 * ld + col;
 #pragma unroll
         for (int q = 0; q < RG; ++q) {
             // rows beyond the band (ragged last group) re-read the band's last row and are not stored
             const int64_t i = (i0 + q < row1) ? i0 + q : row1 - 1;
-            const d2_t t = lpx_ld2<NT>(a.T + i * ld + col);
-            x[q][0] = t[0];
-            x[q][1] = t[1];
+#pragma unroll
+            for (int v = 0; v < CV; ++v) {
+                const d2_t t = lpx_ld2<NT>(a.T + i * ld + col[v]);
+                x[q][2 * v] = t[0];
+                x[q][2 * v + 1] = t[1];
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) eg[q][g] = El[i * TB_KMAX + 16 * g];
             rf[q] = rowflag[i];
@@ -128,55 +139,72 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
         }
         // condensed layout: every case is an fma (the strip in LDS holds 1.0 in the rewritten columns); full layout:
         // unit vectors, general path for the groups and strips that meet one
-        if (cond) Tb2Chain<KB, RG, FULL, 0>::fast(x, eg, prs, cnt, rfany | fxmask, rf, fm0, fm1);
-        else if (rfany == 0u && fxmask == 0u) Tb2Chain<KB, RG, FULL, 0>::fast(x, eg, prs, cnt, 0u, rf, 0u, 0u);
-        else Tb2Chain<KB, RG, FULL, 0>::slow(x, eg, prs, cnt, rf, fm0, fm1, cond);
-        if (live) {
+        if (cond) Tb2Chain<KB, RG, CV, FULL, 0>::fast(x, eg, prs, cnt, rfany | fxmask, rf, fm);
+        else if (rfany == 0u && fxmask == 0u) Tb2Chain<KB, RG, CV, FULL, 0>::fast(x, eg, prs, cnt, 0u, rf, fm);
+        else Tb2Chain<KB, RG, CV, FULL, 0>::slow(x, eg, prs, cnt, rf, fm, cond);
 #pragma unroll
-            for (int q = 0; q < RG; ++q)
-                if (i0 + q < row1) lpx_st2<NT>(p + q * ld, d2_t{x[q][0], x[q][1]});
+        for (int v = 0; v < CV; ++v) {
+            if (live[v]) {
+#pragma unroll
+                for (int q = 0; q < RG; ++q)
+                    if (i0 + q < row1) lpx_st2<NT>(a.T + (i0 + q) * ld + col[v], d2_t{x[q][2 * v], x[q][2 * v + 1]});
+            }
         }
     }
 }
 
-// grid (strips of TB2_COLS columns, bands of rpb rows)
-template <int KB, int NT, int RG, int THREADS = TB2_THREADS>
+// grid (strips of CV * TB2_COLS columns, bands of rpb rows)
+template <int KB, int NT, int RG, int THREADS = TB2_THREADS, int CV = 1>
 __global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
 {
-    __shared__ d2_t prs_all[KB * 64];
+    __shared__ d2_t prs_all[KB * 64 * CV];
     const int cnt = (int)*a.cnt;
     if (cnt <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int64_t col0 = (int64_t)blockIdx.x * TB2_COLS;
-    const int64_t col_own = col0 + 2 * lane;
+    const int64_t col0 = (int64_t)blockIdx.x * (TB2_COLS * CV);
     // every lane stays active (a DPP broadcast from a lane that has left writes nothing): lanes beyond the last column
     // work on column 0's data and store nothing
-    const bool live = col_own < a.cols;
-    const int64_t col = live ? col_own : 0;
-    for (int idx = threadIdx.x; idx < KB * 64; idx += THREADS) {
-        const int u = idx >> 6;
-        const int64_t c = col0 + 2 * (idx & 63);
-        d2_t v = (u < cnt && c < a.cols) ? *(const d2_t *)(a.R + u * a.ldr + c) : d2_t{0.0, 0.0};
+    int64_t col[CV];
+    bool live[CV];
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+        const int64_t c = col0 + v * TB2_COLS + 2 * lane;
+        live[v] = c < a.cols;
+        col[v] = live[v] ? c : 0;
+    }
+    for (int idx = threadIdx.x; idx < KB * 64 * CV; idx += THREADS) {
+        const int u = idx / (64 * CV), v = (idx >> 6) % CV;
+        const int64_t c = col0 + v * TB2_COLS + 2 * (idx & 63);
+        d2_t val = (u < cnt && c < a.cols) ? *(const d2_t *)(a.R + u * a.ldr + c) : d2_t{0.0, 0.0};
         if (a.cond && u < cnt) { // the column this update rewrites receives e itself: fma(e, 1, -0.0)
             const int64_t su = a.pslot[u];
-            if (c == su) v[0] = 1.0;
-            if (c + 1 == su) v[1] = 1.0;
+            if (c == su) val[0] = 1.0;
+            if (c + 1 == su) val[1] = 1.0;
         }
-        prs_all[idx] = v;
+        prs_all[idx] = val;
     }
-    uint32_t fm0 = 0u, fm1 = 0u;
+    uint32_t fm[2 * CV];
+#pragma unroll
+    for (int c = 0; c < 2 * CV; ++c) fm[c] = 0u;
     for (int u = 0; u < cnt; ++u) {
         const int64_t su = a.pslot[u];
-        fm0 |= (uint32_t)(live && col_own == su) << u;
-        fm1 |= (uint32_t)(live && col_own + 1 == su) << u;
+#pragma unroll
+        for (int v = 0; v < CV; ++v) {
+            const int64_t c = col0 + v * TB2_COLS + 2 * lane;
+            fm[2 * v] |= (uint32_t)(live[v] && c == su) << u;
+            fm[2 * v + 1] |= (uint32_t)(live[v] && c + 1 == su) << u;
+        }
     }
+    uint32_t fmany = 0u;
+#pragma unroll
+    for (int c = 0; c < 2 * CV; ++c) fmany |= fm[c];
     uint32_t fxmask = 0u; // wave-uniform: updates that rewrite a column of this strip
     for (int u = 0; u < cnt; ++u)
-        if (__ballot(((fm0 | fm1) >> u) & 1u) != 0ull) fxmask |= 1u << u;
+        if (__ballot((fmany >> u) & 1u) != 0ull) fxmask |= 1u << u;
     __syncthreads();
     const int64_t row0 = (int64_t)blockIdx.y * a.rpb;
     const int64_t row1 = (row0 + a.rpb < a.rows) ? row0 + a.rpb : a.rows;
     const d2_t *prs = prs_all + lane;
-    if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
-    else tb2_walk<KB, NT, RG, false, THREADS>(a, cnt, prs, fm0, fm1, fxmask, col, live, row0, row1);
+    if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
+    else tb2_walk<KB, NT, RG, false, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
 }

@@ -61,11 +61,11 @@ struct Variant {
     const char *name;
     void (*launch)(TbFlushArgs, hipStream_t);
 };
-template <int KB, int NT, int RG, int THREADS>
+template <int KB, int NT, int RG, int THREADS, int CV>
 static void go2(TbFlushArgs a, hipStream_t st)
 {
     // a.rpb = rows per workgroup (band height)
-    hipLaunchKernelGGL((k_tb_flush2<KB, NT, RG, THREADS>), dim3((unsigned)lpx_cdiv(a.cols, TB2_COLS), (unsigned)lpx_cdiv(a.rows, a.rpb)),
+    hipLaunchKernelGGL((k_tb_flush2<KB, NT, RG, THREADS, CV>), dim3((unsigned)lpx_cdiv(a.cols, TB2_COLS * CV), (unsigned)lpx_cdiv(a.rows, a.rpb)),
                        dim3(THREADS), 0, st, a);
 }
 
@@ -117,9 +117,9 @@ int main(int argc, char **argv)
     const double bytes = 16.0 * rows * cols;
     printf("rows %lld cols %lld ld %lld cnt %d: %.3f GB per pass\n", (long long)rows, (long long)cols, (long long)ld, cnt, bytes / 1e9);
 
-#define V2(KB, NT, RG, TH) Variant{"strip128 kb" #KB " nt" #NT " rg" #RG " threads" #TH, go2<KB, NT, RG, TH>}
-    const Variant vs[] = {V2(32, 1, 8, 512), V2(32, 1, 8, 256), V2(32, 1, 4, 256), V2(32, 1, 4, 1024), V2(32, 1, 8, 1024)};
-    const int64_t rpbs[] = {2501, 1251, 640, 320};
+#define V2(KB, NT, RG, TH, CV) Variant{"kb" #KB " nt" #NT " rg" #RG " threads" #TH " colvecs" #CV, go2<KB, NT, RG, TH, CV>}
+    const Variant vs[] = {V2(32, 1, 8, 256, 1), V2(32, 1, 4, 256, 2), V2(32, 1, 2, 256, 4)};
+    const int64_t rpbs[] = {1251, 640, 320, 160};
     for (const Variant &v : vs) {
         for (int64_t rpb : rpbs) {
             a.rpb = rpb;
