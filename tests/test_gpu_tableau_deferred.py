@@ -155,3 +155,23 @@ def test_deferred_chain_dantzig_opt_in_matches_oracle(m, n, seed, monkeypatch):
     assert s.pivot_log().tolist() == want.log.tolist() and res.iters == want.iters
     w = o.nslots + 1
     assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
+
+
+def test_block_entry_points_reject_more_pending_updates_than_the_block(monkeypatch):
+    """lpx_tableau_block_propose / _commit / _flush refuse a pending count or a block size that would lose updates."""
+    import ctypes as C
+
+    from linprog_amd import _lib
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+
+    deferred(monkeypatch, 8)
+    c, A, b, basis = gen.gen_primal(40, 90, 1)
+    eng = PrimalTableauSimplexSolver(c, A, b, basis)._engine
+    lib = _lib.load()
+    assert lib.lpx_tableau_block_size(C.byref(eng.s)) == 8
+    buf = eng.torch.zeros(int(lib.lpx_tableau_msg_len(eng.m)), dtype=eng.torch.float64, device="cuda")
+    assert lib.lpx_tableau_block_propose(C.byref(eng.s), 8, buf.data_ptr(), None) == -1
+    assert lib.lpx_tableau_block_commit(C.byref(eng.s), 9, buf.data_ptr(), 1, None) == -1
+    monkeypatch.setenv("LPX_TABLEAU_BLOCK", "16")
+    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 8, None) == -1
+    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 16, None) == 0
