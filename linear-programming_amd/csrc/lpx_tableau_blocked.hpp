@@ -198,11 +198,24 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 #pragma unroll
         for (int u = 0; u < TB_KMAX; ++u) e[u] = (u < P) ? Eti[u * a.b.lde] : 0.0;
     }
-    if (status != LPX_RUNNING) return;
-    LPX_TB_STAMP(0, 1);
-    // entering variable (primal_solvers.py:135-142) and its column slot
+    // entering variable (primal_solvers.py:135-142) and its column slot; the scan of the pricing partials goes out with the
+    // other loads (valid addresses whatever the status)
     TbCand c{LPX_INF, LPX_NOIDX, -1};
     int64_t win = 0;
+    if (MODE != TB_SELECT) {
+        for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
+            const double v = a.price.v0[k];
+            const int64_t id = a.price.i0[k], sl = a.price.i1[k];
+            if (s.pricing == LPX_PRICE_DANTZIG) {
+                if (vi_less(v, id, c.mn, c.var)) c = TbCand{v, id, sl};
+            } else {
+                c.mn = fmin(c.mn, v);
+                if (id < c.var) { c.var = id; c.slot = sl; }
+            }
+        }
+    }
+    if (status != LPX_RUNNING) return;
+    LPX_TB_STAMP(0, 1);
     if (MODE == TB_SELECT) { // lowest global index over the ranks' candidates (a handful of ranks: every thread scans them)
         for (int64_t g = 0; g < a.nranks; ++g) {
             const double v = a.recv[g * a.msg];
@@ -216,16 +229,6 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         }
         c.slot = (c.var == LPX_NOIDX) ? -1 : t_slot(s, c.var); // -1: the column lives on another rank
     } else {
-        for (int64_t k = tid; k < a.nprice; k += TB_THREADS) {
-            const double v = a.price.v0[k];
-            const int64_t id = a.price.i0[k], sl = a.price.i1[k];
-            if (s.pricing == LPX_PRICE_DANTZIG) {
-                if (vi_less(v, id, c.mn, c.var)) c = TbCand{v, id, sl};
-            } else {
-                c.mn = fmin(c.mn, v);
-                if (id < c.var) { c.var = id; c.slot = sl; }
-            }
-        }
         LPX_TB_STAMP(0, 2);
         c = tb_price_reduce(s.pricing, c, sh_price);
     }
@@ -314,9 +317,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int l32 = tid & 31; // lane l holds pending update l's pivot row / rewritten column / multiplier of row r
     const int pv = (l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2;
     const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
-    if (status != LPX_RUNNING) return;
-    LPX_TB_STAMP(1, 1);
-    // leaving row: first minimum ratio over the workgroups' partials (primal_solvers.py:166, np.argmin), each with its payload
+    const int64_t pivots0 = ctrl->pivots; // used by the bookkeeping thread only
+    // the ratio partials too (their addresses are valid whatever the status): leaving row = first minimum ratio over the
+    // workgroups' partials (primal_solvers.py:166, np.argmin), each with its payload
     TbRatio best{LPX_INF, LPX_NOIDX, -LPX_INF, 0.0, 0.0, -1};
     for (int64_t k = tid; k < a.nratio; k += TB_THREADS) {
         const TbRatio t{a.ratio.v0[k], a.ratio.i0[k], a.ratio.v1[k], a.b.dbest[k], a.b.xbest[k], a.ratio.i1[k]};
@@ -324,6 +327,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         if (vi_less(t.th, t.row, best.th, best.row)) best = t;
         best.dmax = dm;
     }
+    if (status != LPX_RUNNING) return;
+    LPX_TB_STAMP(1, 1);
     LPX_TB_STAMP(1, 2);
     const TbRatio w = tb_ratio_reduce(best, sh_ratio);
     LPX_TB_STAMP(1, 3);
@@ -390,13 +395,22 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     LPX_TB_STAMP(1, 7);
     if (g == 0) { // bookkeeping of the basis change (primal_solvers.py:96-108, :261)
         s.basis[r] = j;
-        t_swap_columns(s, j, leaving);
-        if (s.log && ctrl->pivots < s.log_cap) {
-            s.log[3 * ctrl->pivots + 0] = r;
-            s.log[3 * ctrl->pivots + 1] = j;
-            s.log[3 * ctrl->pivots + 2] = leaving;
+        if (s.slot_var) { // t_swap_columns without its look-up: the entering variable's slot is `slot` (-1: another rank's)
+            if (slot >= 0) {
+                s.slot_var[slot] = leaving;
+                s.var_slot[leaving] = slot;
+            }
+            s.var_slot[j] = -1;
+            ctrl->enter_slot = slot;
+        } else {
+            t_swap_columns(s, j, leaving);
         }
-        ctrl->pivots += 1;
+        if (s.log && pivots0 < s.log_cap) {
+            s.log[3 * pivots0 + 0] = r;
+            s.log[3 * pivots0 + 1] = j;
+            s.log[3 * pivots0 + 2] = leaving;
+        }
+        ctrl->pivots = pivots0 + 1;
         ctrl->leave_r = r;
         ctrl->leave_var = leaving;
         ctrl->ratio_val = w.th;
