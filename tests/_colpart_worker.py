@@ -67,6 +67,90 @@ def numpy_rank(c, A, b, basis, rank, world, ex, maxiters):
     return log, basis, T[:m, nl].copy(), False
 
 
+def numpy_rank_deferred(c, A, b, basis, rank, world, ex, maxiters, kb=5):
+    """The same protocol with DEFERRED updates (lpx_tableau_block_*): the slice T0 stays stale for up to kb pivots; the
+    proposal's column and the commit's pivot row are formed from T0 plus the pending (r, e, pivot row) triples with the
+    update's own arithmetic (the oracle's rank-1 helper on the thin piece), the reduced-cost row and x_B are kept current,
+    and a "flush" applies the pending updates to T0 in order.  Same messages, same decisions, same bits as numpy_rank."""
+    c32, A32, b32 = O.preprocess(c, A, b)
+    m, n = A32.shape
+    j0, j1 = column_range(n, rank, world)
+    nl = j1 - j0
+    T0 = np.zeros((m + 1, nl + 1))
+    T0[:m, :nl] = A32[:, j0:j1]
+    T0[:m, nl] = b32
+    T0[m, :nl] = c32[j0:j1]
+    basis = np.array(basis, dtype=np.int64)
+    log, f32, pend = [], True, []  # pend: (r, e, old pivot row over the local columns + x_B, local rewritten column or -1)
+    rc, xb = T0[m, :nl].copy(), T0[:m, nl].copy()
+
+    def column(k):  # column k of the slice as the pending updates leave it
+        d = T0[:, k:k + 1].copy()
+        for r, e, row, kk in pend:
+            if kk == k:
+                d[:] = 0.0
+                d[r] = 1.0
+            else:
+                d = O.rank1_update(np.ascontiguousarray(d), r, e)  # d[r] is the old pivot-row entry of this column
+        return d[:, 0]
+
+    def pivot_row(r):  # row r of the slice (and its x_B entry) as the pending updates leave it
+        x = T0[r:r + 1, :].copy()
+        for ru, e, row, kk in pend:
+            if ru == r:
+                x = O.rank1_update(np.ascontiguousarray(row[None, :].copy()), 0, np.array([e[ru]]))
+            else:
+                x = O.rank1_update(np.ascontiguousarray(np.vstack([x, row[None, :]])), 1, np.array([e[r], e[ru]]))[:1]
+            if kk >= 0:
+                x[0, kk] = 1.0 if ru == r else 0.0
+        return x[0]
+
+    def flush():
+        nonlocal T0
+        for r, e, row, kk in pend:
+            T0 = O.rank1_update(np.ascontiguousarray(T0), r, e)
+            if kk >= 0:
+                T0[:, kk] = 0.0
+                T0[r, kk] = 1.0
+        pend.clear()
+
+    for it in range(maxiters):
+        neg = np.flatnonzero(rc < 0)
+        send = np.zeros(ex.msg)
+        send[0] = rc.min() if nl else np.inf
+        send[1] = j0 + neg[0] if neg.size else NOIDX
+        if neg.size:
+            send[2:2 + m + 1] = column(int(neg[0]))
+        ex.sendbuf.copy_(torch.from_numpy(send))
+        recv = ex.all_gather().numpy().reshape(world, ex.msg)
+        mn = recv[:, 0].min()
+        if mn >= 0 or abs(mn) <= 1e-8:
+            flush()
+            assert np.array_equal(T0[m, :nl], rc) and np.array_equal(T0[:m, nl], xb)  # the eager pieces are the tableau's
+            return log, basis, xb.copy(), True
+        win = int(np.argmin(recv[:, 1]))
+        j = int(recv[win, 1])
+        d = recv[win, 2:2 + m + 1]
+        r, theta, dmax = O.ratio_primal(xb.copy(), d[:m].copy(), f32)
+        e = (-d) / d[r]
+        e[r] = 1.0 / d[r]
+        row = pivot_row(r)
+        kk = j - j0 if j0 <= j < j1 else -1
+        # eager pieces, with the update's own arithmetic: x_B (column nl) and the reduced-cost row (row m)
+        xb = O.rank1_update(np.ascontiguousarray(np.append(xb, 0.0)[:, None]), r, e)[:m, 0]
+        rc = O.rank1_update(np.ascontiguousarray(np.vstack([rc[None, :], row[None, :nl]])), 1, np.array([e[m], e[r]]))[0]
+        if kk >= 0:
+            rc[kk] = 0.0
+        pend.append((r, e.copy(), row, kk))
+        log.append([r, j, int(basis[r])])
+        basis[r] = j
+        f32 = False
+        if len(pend) == kb:
+            flush()
+    flush()
+    return log, basis, xb.copy(), False
+
+
 def numpy_rank_dual(c, A, b, basis, rank, world, ex, maxiters):
     """Column-partitioned DUAL tableau simplex with NumPy standing in for lpx_tableau_dual_propose/commit."""
     c32, A32, b32 = O.preprocess(c, A, b)
@@ -236,9 +320,9 @@ def main():
         return
     c, A, b, basis = problems.gen_primal(m, n, seed)
     want = O.OracleRevised(c, A, b, basis, log_cap=maxiters + 1).solve(maxiters)
-    if mode == "cpu":
+    if mode in ("cpu", "cpu-deferred"):
         ex = ProposalExchange(dist.group.WORLD, m + 3 + ((m + 3) % 2), "cpu")
-        log, bas, xB, opt = numpy_rank(c, A, b, basis, rank, world, ex, maxiters)
+        log, bas, xB, opt = (numpy_rank if mode == "cpu" else numpy_rank_deferred)(c, A, b, basis, rank, world, ex, maxiters)
         assert log == want.log.tolist(), f"rank {rank}: pivot sequence differs"
         assert bas.tolist() == want.basis.tolist() and opt == (want.status == O.OPTIMAL)
     else:

@@ -32,6 +32,13 @@ def test_protocol_cpu_gloo(nproc, m, n):
     _run("cpu", nproc, m, n, 1, 100000)
 
 
+@pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
+def test_protocol_deferred_updates_cpu_gloo(nproc, m, n):
+    """The exchange with deferred updates (lpx_tableau_block_*), NumPy model on CPU: proposals and pivot rows formed from
+    the stale slice plus the pending updates, flush every 5 pivots -- the oracle's pivot sequence on every rank."""
+    _run("cpu-deferred", nproc, m, n, 1, 100000)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,m,n", [(2, 64, 128), (3, 50, 121)])
 def test_product_path_two_ranks_one_gpu(nproc, m, n):
