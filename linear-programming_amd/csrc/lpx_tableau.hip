@@ -1391,14 +1391,15 @@ static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q
     f.T = s->T; f.rows = s->m + 1; f.cols = s->n + 1; f.ld = s->ld; f.cond = s->slot_var != nullptr;
     f.E = w.tb.E; f.R = w.tb.R; f.ldr = w.tb.ldr; f.pslot = w.tb.pslot; f.rowflag = w.tb.rowflag; f.cnt = w.tb.cnt;
     const int64_t nstrips = lpx_cdiv(f.cols, TB2_COLS);
+    const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
     int64_t rpb = lpx_env_int("LPX_TB_ROWS", 0);
     if (rpb <= 0) {
-        int64_t nbands = lpx_cdiv(5120, nstrips);
+        // workgroups to aim for: the condensed layout's blocks of 32 run 4 workgroups per CU (lpx_tb_flush32.hip), the rest 2
+        int64_t nbands = lpx_cdiv(lpx_env_int("LPX_TB_WGS", (KB == 32 && nt && f.cond) ? 20480 : 5120), nstrips);
         if (nbands < 1) nbands = 1;
         rpb = lpx_roundup(lpx_cdiv(f.rows, nbands), 32);
     }
     f.rpb = rpb;
-    const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
     lpx_k1_begin(q);
     lpx_tb_flush_launch(f, KB, nt, q);
     lpx_k1_end(q);

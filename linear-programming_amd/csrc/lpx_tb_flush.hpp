@@ -104,7 +104,7 @@ struct Tb2Chain<KB, RG, CV, FULL, KB> {
                                                 const uint32_t (&)[RG], const uint32_t (&)[2 * CV], bool) {}
 };
 
-template <int KB, int NT, int RG, bool FULL, int THREADS, int CV>
+template <int KB, int NT, int RG, bool FULL, int THREADS, int CV, int ONLY = 0>
 __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2_t *prs, const uint32_t (&fm)[2 * CV], uint32_t fxmask,
                                          const int64_t (&col)[CV], const bool (&live)[CV], int64_t row0, int64_t row1)
 {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
         }
         // condensed layout: every case is an fma (the strip in LDS holds 1.0 in the rewritten columns); full layout:
         // unit vectors, general path for the groups and strips that meet one
-        if (cond) Tb2Chain<KB, RG, CV, FULL, 0>::fast(x, eg, prs, cnt, rfany | fxmask, rf, fm);
+        if (ONLY == 1 || cond) Tb2Chain<KB, RG, CV, FULL, 0>::fast(x, eg, prs, cnt, rfany | fxmask, rf, fm);
         else if (rfany == 0u && fxmask == 0u) Tb2Chain<KB, RG, CV, FULL, 0>::fast(x, eg, prs, cnt, 0u, rf, fm);
         else Tb2Chain<KB, RG, CV, FULL, 0>::slow(x, eg, prs, cnt, rf, fm, cond);
 #pragma unroll
@@ -154,12 +154,16 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
 }
 
 // grid (strips of CV * TB2_COLS columns, bands of rpb rows)
-template <int KB, int NT, int RG, int THREADS = TB2_THREADS, int CV = 1>
+// ONLY = 1: the condensed layout's full blocks alone (every case an fma: the instance whose register count decides the
+// occupancy of the large-tableau loop); ONLY = 2: everything else; 0: both in one kernel
+template <int KB, int NT, int RG, int THREADS = TB2_THREADS, int CV = 1, int ONLY = 0>
 __global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
 {
     __shared__ d2_t prs_all[KB * 64 * CV];
     const int cnt = (int)*a.cnt;
     if (cnt <= 0) return;
+    if (ONLY == 1 && (cnt != KB || !a.cond)) return;
+    if (ONLY == 2 && cnt == KB && a.cond) return;
     const int lane = threadIdx.x & 63;
     const int64_t col0 = (int64_t)blockIdx.x * (TB2_COLS * CV);
     // every lane stays active (a DPP broadcast from a lane that has left writes nothing): lanes beyond the last column
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
     const int64_t row0 = (int64_t)blockIdx.y * a.rpb;
     const int64_t row1 = (row0 + a.rpb < a.rows) ? row0 + a.rpb : a.rows;
     const d2_t *prs = prs_all + lane;
-    if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
+    if (ONLY == 1) tb2_walk<KB, NT, RG, true, THREADS, CV, 1>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
+    else if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
     else tb2_walk<KB, NT, RG, false, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
 }
