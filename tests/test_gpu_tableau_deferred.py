@@ -70,6 +70,29 @@ def test_deferred_chain_bit_exact_vs_oracle(m, n, condensed, kb, rows, monkeypat
             assert np.array_equal(s._engine.slot_var.cpu().numpy(), o.slot_var)
 
 
+@pytest.mark.parametrize("rows", [None, 7, 64])
+@pytest.mark.parametrize("m,n,condensed", [(300, 700, True), (530, 1061, True), (700, 760, True), (300, 700, False)])
+def test_deferred_pass_large_tableau_instances_bit_exact_vs_oracle(m, n, condensed, rows, monkeypatch):
+    """The instances the pass uses on tableaus beyond 192 MiB (non-temporal streams; blocks of 32: the condensed layout's
+    full blocks in a kernel of their own, short blocks and the full layout in its twin -- lpx_tb_flush32.hip), forced on at
+    a size the oracle finishes in seconds: full blocks, a short last block and calls that end inside a block."""
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    deferred(monkeypatch, 32, rows)
+    monkeypatch.setenv("LPX_RANK1_NT", "1")
+    c, A, b, basis = gen.gen_primal(m, n, 11)
+    s = logged(PrimalTableauSimplexSolver, 1024)(c, A, b, basis, condensed=condensed)
+    o = O.OracleTableau(c, A, b, basis, condensed=condensed, log_cap=1024)
+    for k in (64, 32, 5, 27, 100, 7):
+        res = s.solve(k)
+        r = o.solve(k)
+        assert s.pivot_log().tolist() == o.log[:len(s.pivot_log())].tolist()
+        w = o.nslots + 1
+        assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
+        assert res.basis.tolist() == r.basis.tolist() and res.iters == r.iters and np.array_equal(res.x, r.x)
+
+
 @pytest.mark.parametrize("kb", [8, 32])
 def test_deferred_chain_equals_the_eager_chains_bit_for_bit(kb, monkeypatch):
     """The same LP through the deferred chain and through the in-place three-kernel chain: identical tableaus."""
