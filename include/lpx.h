@@ -133,8 +133,10 @@ typedef struct lpx_tableau {
     /* Optional second buffer of the size of T ((m+1) x ld doubles, 16-byte aligned), or NULL.  With it, lpx_tableau_iterate
      * and lpx_tableau_dual_iterate run tableaus of up to 16384 rows and 32767 columns as ONE launch per pivot: the
      * tableau ping-pongs between T and T_alt while lookahead workgroups of the same launch prepare the next pivot's
-     * decisions (lpx_tableau.hip).  The state is in T again whenever a call returns; T_alt's contents are scratch
-     * between calls.  Same arithmetic, same bits. */
+     * decisions (lpx_tableau.hip).  Large tableaus (lpx_tableau_pipelined() != 0) use it for the PIPELINED deferred-update
+     * chain instead: the pass over the tableau streams T -> T_alt (then back) while the next block's pivots are decided
+     * beside it.  The state is in T again whenever a call's work has drained; T_alt's contents are scratch between
+     * calls.  Same arithmetic, same bits. */
     double *T_alt;
 } lpx_tableau;
 
@@ -252,10 +254,17 @@ int64_t lpx_tableau_workspace_bytes(int64_t m, int64_t n);
  * one pass over T applies those rank-1 updates to every element in order -- the arithmetic of :247-253 element by
  * element, bit for bit, with 1/block of the HBM traffic.  T holds the current state whenever a call returns. */
 int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream);
-/* Pivots per pass over the tableau that lpx_tableau_iterate uses for this state (LPX_TABLEAU_BLOCK: 8, 16 or 32; default
- * 32 from 192 MiB on, else 16; for tableaus of at least LPX_TABLEAU_BLOCK_MIN_MB, default 48), or 0: one update per pivot.  No counterpart in the
- * reference (it recomputes from B^-1 every iteration); a scheduling parameter, not a numerical one. */
+/* Pivots per pass over the tableau that lpx_tableau_iterate uses for this state: 0 (one update per pivot) when
+ * 8 (m+1)(n+1) bytes < LPX_TABLEAU_BLOCK_MIN_MB MiB (default 48); else LPX_TABLEAU_BLOCK if it is set to 8, 16 or 32
+ * (any other value: 0); else 32 from 192 MiB on and 16 below.  No counterpart in the reference (it recomputes from B^-1
+ * every iteration); a scheduling parameter, not a numerical one. */
 int64_t lpx_tableau_block_size(const lpx_tableau *s);
+/* 1 when lpx_tableau_iterate runs this state's deferred-update chain PIPELINED: blocks are in use, T_alt is set, the
+ * tableau is unpartitioned and 8 (m+1)(n+1) bytes >= LPX_TABLEAU_PIPELINE_MIN_MB MiB (default 1024; negative: never).  The pass of block k
+ * then writes the other buffer on the caller's stream while block k+1 is decided, on a stream of the library's own, from
+ * the buffer the pass reads plus the pending pairs of both blocks: a block costs max(pass, decisions) instead of their
+ * sum.  Same arithmetic element by element (primal_solvers.py:247-253), same bits; a scheduling parameter. */
+int lpx_tableau_pipelined(const lpx_tableau *s);
 /* Column-partitioned step, part 1: local pricing over owned columns and candidate pivot column.
  * sendbuf[0] = local min rc, sendbuf[1] = global index of the first owned column with rc<0 (or 2^62),
  * sendbuf[2 .. 2+m] = that column of T (m entries + its reduced cost).  Length lpx_tableau_msg_len(m). */

@@ -87,6 +87,7 @@ _SIGS = {
     "lpx_tableau_iterate": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
     "lpx_tableau_msg_len": (i64, [i64]),
     "lpx_tableau_block_size": (i64, [C.POINTER(LpxTableau)]),
+    "lpx_tableau_pipelined": (C.c_int, [C.POINTER(LpxTableau)]),
     "lpx_tableau_propose": (C.c_int, [C.POINTER(LpxTableau), vp, C.c_int, vp]),
     "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
     "lpx_tableau_commit_begin": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp, vp]),

@@ -36,6 +36,7 @@ struct TabWs {
     int64_t *base;   // pivots at the start of the current lpx_tableau_iterate call
     double *pend;    // partitioned dual loop with lookahead: {leaving row, optimal?, min x_B} decided one pivot ahead
     TbWs tb;         // deferred-update chain (lpx_tableau_blocked.hpp)
+    TbWs tb2;        // pipelined chain: the pending pairs of every other block (E, Et, R, prow, pslot, rowflag, cnt of its own)
     int64_t bytes;
 };
 static inline char *tcarve(char *&p, int64_t bytes)
@@ -86,6 +87,15 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
     w.tb.scal = (double *)tcarve(p, 8 * 16);
     w.tb.dbest = (double *)tcarve(p, 8 * LPX_MAXP);
     w.tb.xbest = (double *)tcarve(p, 8 * LPX_MAXP);
+    w.tb.tsel = (int64_t *)tcarve(p, 8 * 2);
+    w.tb2 = w.tb;
+    w.tb2.E = (double *)tcarve(p, 8 * (m + 2) * TB_KMAX);
+    w.tb2.Et = (double *)tcarve(p, 8 * w.tb.lde * TB_KMAX);
+    w.tb2.R = (double *)tcarve(p, 8 * w.tb.ldr * TB_KMAX);
+    w.tb2.prow = (int64_t *)tcarve(p, 8 * TB_KMAX);
+    w.tb2.pslot = (int64_t *)tcarve(p, 8 * TB_KMAX);
+    w.tb2.rowflag = (uint32_t *)tcarve(p, 4 * (m + 2));
+    w.tb2.cnt = (int64_t *)tcarve(p, 8 * 2);
     w.bytes = (int64_t)(p - (char *)base);
     return w;
 }
@@ -1385,11 +1395,11 @@ static void tb_boot(const lpx_tableau *s, const TbArgs &a, hipStream_t st)
 // the pass over the tableau: strips of 128 columns x bands of rows; a workgroup (4 waves) walks down its band 32 rows at a
 // time, so bands are whole multiples of 32 rows, and there are enough of them for ~5000 workgroups (measured on the
 // 20001 x 20001 tableau, tools/tb_flush_bench.hip: bands of 2501 / 1251 / 640 / 320 rows -> 1.21 / 1.18 / 1.17 / 1.17 ms)
-static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q)
+static void tb_flush_from(const lpx_tableau *s, const TbWs &h, const double *src, double *dst, int KB, hipStream_t q)
 {
     TbFlushArgs f{};
-    f.T = s->T; f.rows = s->m + 1; f.cols = s->n + 1; f.ld = s->ld; f.cond = s->slot_var != nullptr;
-    f.E = w.tb.E; f.R = w.tb.R; f.ldr = w.tb.ldr; f.pslot = w.tb.pslot; f.rowflag = w.tb.rowflag; f.cnt = w.tb.cnt;
+    f.T = src; f.Tdst = dst; f.rows = s->m + 1; f.cols = s->n + 1; f.ld = s->ld; f.cond = s->slot_var != nullptr;
+    f.E = h.E; f.R = h.R; f.ldr = h.ldr; f.pslot = h.pslot; f.rowflag = h.rowflag; f.cnt = h.cnt;
     const int64_t nstrips = lpx_cdiv(f.cols, TB2_COLS);
     const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
     int64_t rpb = lpx_env_int("LPX_TB_ROWS", 0);
@@ -1404,6 +1414,7 @@ static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q
     lpx_tb_flush_launch(f, KB, nt, q);
     lpx_k1_end(q);
 }
+static void tb_flush(const lpx_tableau *s, const TabWs &w, int KB, hipStream_t q) { tb_flush_from(s, w.tb, s->T, s->T, KB, q); }
 
 static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
 {
@@ -1416,7 +1427,7 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
         TbArgs b = a;
         b.u = (int)(it % KB);
         hipLaunchKernelGGL((k_tb_column<TB_LOCAL>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
-        hipLaunchKernelGGL(k_tb_prepare, dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
+        hipLaunchKernelGGL((k_tb_prepare<false>), dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
         it += 1;
     };
     struct {
@@ -1433,6 +1444,152 @@ static int tableau_iterate_blocked(const lpx_tableau *s, const TabWs &w, int64_t
         if (rc) return rc;
         flush(st);
         iters -= k;
+    }
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
+// ---- pipelined chain: the pass of block k streams T_old -> T_new on the caller's stream while block k+1 is decided on a
+// high-priority side stream from T_old, block k's pairs and its own (lpx_tableau_blocked.hpp).  Dependencies, all by
+// events, none through the host:  D(k+1) after D(k) [same stream] and F(k-1) [T_old complete, its pair arrays free];
+// F(k) after D(k) and F(k-1) [same stream].  Buffers alternate T, T_alt, T, ...; the LAST pass of a call writes T whatever
+// it reads (nothing is decided beside it, so it may run in place), and a closing kernel copies T_alt back in the one case
+// the host cannot see from here: a loop that ended inside an earlier block (TbWs::tsel).  T is current when the call's
+// work has drained, as for every other chain.
+struct TbPipe {
+    int dev;
+    hipStream_t side;  // decisions
+    hipStream_t pass;  // the pass, when the two run on disjoint sets of CUs (else the caller's stream carries it)
+    hipEvent_t fork, join, evD[4], evF[4];
+};
+static std::mutex g_tb_pipe_mu;
+static TbPipe g_tb_pipes[64];
+static int g_tb_npipes = 0;
+// The pass keeps every wave slot of the chip busy for a millisecond; a decision workgroup needs four free slots and
+// 128+ free registers on each SIMD of ONE CU at the same moment, which a retiring pass workgroup never leaves (its
+// successor takes them first): beside the pass the decision kernels starve until it drains, whatever the stream
+// priorities (rocprofv3 trace, profiles/r03_pipe_overlap_nomask.txt).  So the two get disjoint CUs: LPX_TB_PIPE_CUS (default
+// 32 of 256) for the decisions -- the low bits of the mask, which the driver deals round-robin over the XCDs and their
+// shader engines -- and the rest for the pass.  0: no masks, one high-priority side stream.
+static int tb_pipe_get(TbPipe **out)
+{
+    int dev = 0;
+    LPX_HIP(hipGetDevice(&dev));
+    for (int k = 0; k < g_tb_npipes; ++k)
+        if (g_tb_pipes[k].dev == dev) { *out = &g_tb_pipes[k]; return LPX_OK; }
+    LPX_REQUIRE(g_tb_npipes < 64, "more than 64 devices");
+    TbPipe p{};
+    p.dev = dev;
+    hipDeviceProp_t prop;
+    LPX_HIP(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    int res = lpx_env_int("LPX_TB_PIPE_CUS", 32);
+    if (res < 0 || 2 * res > ncu || ncu > 1024) res = 0;
+    if (res > 0) {
+        uint32_t md[32] = {0}, mp[32] = {0};
+        for (int c = 0; c < ncu; ++c) (c < res ? md : mp)[c / 32] |= 1u << (c % 32);
+        const uint32_t words = (uint32_t)((ncu + 31) / 32);
+        if (hipExtStreamCreateWithCUMask(&p.side, words, md) != hipSuccess || hipExtStreamCreateWithCUMask(&p.pass, words, mp) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p.side) (void)hipStreamDestroy(p.side);
+            p.side = p.pass = nullptr;
+            res = 0;
+        }
+    }
+    if (res == 0) {
+        int lo = 0, hi = 0;
+        LPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); // hi = greatest priority (numerically lowest)
+        LPX_HIP(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, hi));
+    }
+    LPX_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+    LPX_HIP(hipEventCreateWithFlags(&p.join, hipEventDisableTiming));
+    for (int k = 0; k < 4; ++k) {
+        LPX_HIP(hipEventCreateWithFlags(&p.evD[k], hipEventDisableTiming));
+        LPX_HIP(hipEventCreateWithFlags(&p.evF[k], hipEventDisableTiming));
+    }
+    g_tb_pipes[g_tb_npipes] = p;
+    *out = &g_tb_pipes[g_tb_npipes++];
+    return LPX_OK;
+}
+__global__ __launch_bounds__(256) void k_tb_syncback(const int64_t *tsel, const double *src, double *dst, int64_t npairs)
+{
+    if (tsel[0] == 0) return;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < npairs; k += (int64_t)gridDim.x * 256)
+        lpx_st2<1>(dst + 2 * k, lpx_ld2<1>(src + 2 * k));
+}
+// tableaus whose pass is long enough to hide a block's decisions behind it (they pay chains of up to 2 KB for it)
+static inline bool t_use_pipeline(const lpx_tableau *s)
+{
+    if (s->T_alt == nullptr || s->T_alt == s->T) return false;
+    if (!(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n))) return false;
+    const int64_t bytes = 8 * (s->m + 1) * (s->n + 1);
+    const int min_mb = lpx_env_int("LPX_TABLEAU_PIPELINE_MIN_MB", 1024); // negative: never
+    return min_mb >= 0 && bytes >= ((int64_t)min_mb << 20);
+}
+extern "C" int lpx_tableau_pipelined(const lpx_tableau *s)
+{
+    if (s == nullptr || s->m <= 0 || s->n <= 0) return 0;
+    return (t_block_size(s) > 0 && t_use_pipeline(s)) ? 1 : 0;
+}
+static int tableau_iterate_pipelined(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st, int KB)
+{
+    LPX_REQUIRE(lpx_aligned16(s->T_alt), "T_alt must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(g_tb_pipe_mu);
+    TbPipe *pp = nullptr;
+    int rc = tb_pipe_get(&pp);
+    if (rc) return rc;
+    hipStream_t sd = pp->side;
+    hipStream_t sf = pp->pass ? pp->pass : st; // the stream of the passes
+    const int64_t nprep = lpx_cdiv(t_prep_len(s), TB_THREADS);
+    const int64_t nb = lpx_cdiv(iters, KB);
+    double *buf[2] = {s->T, s->T_alt};
+    LPX_HIP(hipEventRecord(pp->fork, st));
+    LPX_HIP(hipStreamWaitEvent(sd, pp->fork, 0));
+    if (sf != st) LPX_HIP(hipStreamWaitEvent(sf, pp->fork, 0));
+    tb_boot(s, tb_args(s, w), sd);
+    struct {
+        lpx_tableau s;
+        int kb, what;
+    } key;
+    for (int64_t k = 0; k < nb; ++k) {
+        const int64_t cnt = (k + 1 < nb) ? KB : iters - k * KB;
+        const int srcid = (int)(k & 1), dstid = (k + 1 == nb) ? 0 : (srcid ^ 1);
+        TbArgs a = tb_args(s, w);
+        a.b = (k & 1) ? w.tb2 : w.tb;
+        a.o = (k & 1) ? w.tb : w.tb2;
+        a.uo = k > 0 ? KB : 0;
+        a.dstid = dstid;
+        if (k > 0) a.s.T = buf[(k - 1) & 1]; // the source of the pass in flight
+        if (k >= 2) LPX_HIP(hipStreamWaitEvent(sd, pp->evF[(k - 2) & 3], 0));
+        int64_t it = 0;
+        const bool old = k > 0;
+        auto one = [&](hipStream_t q) {
+            TbArgs b = a;
+            b.u = (int)(it % KB);
+            if (old) {
+                hipLaunchKernelGGL((k_tb_column<TB_LOCAL, true>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
+                hipLaunchKernelGGL((k_tb_prepare<true>), dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
+            } else {
+                hipLaunchKernelGGL((k_tb_column<TB_LOCAL>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, q, b);
+                hipLaunchKernelGGL((k_tb_prepare<false>), dim3((unsigned)nprep), dim3(TB_THREADS), 0, q, b);
+            }
+            it += 1;
+        };
+        memset(&key, 0, sizeof key);
+        key.s = a.s; key.kb = KB;
+        key.what = 16 + (old ? 1 : 0) + 2 * (int)(k & 1) + 4 * dstid;
+        rc = lpx_run_iterations(&key, sizeof key, cnt, sd, one, KB, true);
+        if (rc) return rc;
+        LPX_HIP(hipEventRecord(pp->evD[k & 3], sd));
+        LPX_HIP(hipStreamWaitEvent(sf, pp->evD[k & 3], 0));
+        tb_flush_from(s, a.b, buf[srcid], buf[dstid], KB, sf);
+        LPX_HIP(hipEventRecord(pp->evF[k & 3], sf));
+    }
+    const int64_t npairs = (s->m + 1) * s->ld / 2;
+    hipLaunchKernelGGL(k_tb_syncback, dim3(4096), dim3(256), 0, sf, (const int64_t *)w.tb.tsel, (const double *)s->T_alt, s->T, npairs);
+    if (sf != st) {
+        LPX_HIP(hipEventRecord(pp->join, sf));
+        LPX_HIP(hipStreamWaitEvent(st, pp->join, 0));
     }
     LPX_LAUNCH_CHECK();
     return LPX_OK;
@@ -1480,7 +1637,7 @@ extern "C" int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, c
     a.msg = lpx_tableau_msg_len(s->m);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((k_tb_column<TB_SELECT>), dim3((unsigned)a.nratio), dim3(TB_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_tb_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(s), TB_THREADS)), dim3(TB_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_tb_prepare<false>), dim3((unsigned)lpx_cdiv(t_prep_len(s), TB_THREADS)), dim3(TB_THREADS), 0, st, a);
     LPX_LAUNCH_CHECK();
     return LPX_OK;
 }
@@ -1504,7 +1661,11 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
     if (iters <= 0) return LPX_OK;
-    if (const int kb = t_block_size(s)) return tableau_iterate_blocked(s, w, iters, st, kb);
+    if (const int kb = t_block_size(s)) {
+        // one block has nothing to overlap with: the in-place chain (shorter chains, no second buffer touched)
+        if (t_use_pipeline(s) && iters > kb) return tableau_iterate_pipelined(s, w, iters, st, kb);
+        return tableau_iterate_blocked(s, w, iters, st, kb);
+    }
     if (t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");

@@ -29,6 +29,13 @@
 //     k_tb_flush:      T <- T with the cnt pending updates applied, in order; R strips in registers, e_u[i] wave-uniform
 // No kernel reads a word that the same launch writes: cnt / rowflag are written by k_tb_prepare (and cleared by
 // k_tb_column(0), also when the loop has ended, so a later flush applies nothing), read by k_tb_flush only.
+//
+// PIPELINED chain (unpartitioned tableaus with a second buffer, tableau_iterate_pipelined in lpx_tableau.hip).  The pass
+// and the next block's decisions have nothing to wait for in each other if the pass writes ANOTHER buffer: while pass k
+// streams T_old -> T_new, block k+1 is decided from T_old, the KB pairs of block k (complete, read-only by now) and its
+// own u pairs -- the same chain, KB + u long.  Every workspace array of a block's pairs exists twice (TbArgs::b = this
+// block's, TbArgs::o = the previous block's); rc[], xb[] and the partials belong to the decisions alone.  A step then
+// costs max(pass, decisions) instead of their sum.
 #pragma once
 
 #include "lpx_tableau_blocked_decl.hpp"
@@ -59,6 +66,11 @@ struct TbArgs {
     double *d;
     int64_t nprice, nratio;
     int u;
+    // pipelined chain (OLD instances of the two per-pivot kernels): s.T is the tableau as it stood BEFORE the block whose
+    // pass is still in flight; that block's uo (eta column, pivot row) pairs come first in every chain, then the u of
+    // this block.  dstid: the buffer this block's pass writes (TbWs::tsel)
+    TbWs o;
+    int uo, dstid;
     // column-partitioned tableau: this rank's proposal (written) / the gathered proposals of all ranks (read)
     double *sendbuf;
     const double *recv;
@@ -131,7 +143,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
     __shared__ TbCand sh_price[TB_THREADS / 64];
     const lpx_tableau &s = a.s;
     const int64_t g = (int64_t)blockIdx.x * TB_THREADS + threadIdx.x;
-    if (g == 0) *a.b.cnt = 0;
+    if (g == 0) {
+        *a.b.cnt = 0;
+        a.b.tsel[0] = 0; // a call starts (and ends) with the tableau in T
+    }
     if (s.ctrl->status != LPX_RUNNING) return;
     if (g < s.m) a.b.xb[g] = s.T[g * s.ld + s.n];
     if ((int64_t)blockIdx.x >= a.nprice) return;
@@ -151,22 +166,36 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_boot(TbArgs a)
 
 // entry i of column `slot` after the P pending updates: the column an update rewrote is a wave-uniform case, the pivot
 // row of an update is the same fma on an accumulator of -0.0 (fma(e, R, -0.0) == e * R bit for bit)
-__device__ __forceinline__ double tb_column_chain(double di, int P, int slot, int i, int sv, int pv, const double (&e)[TB_KMAX], double rv,
+// e[k] belongs to update U0 + k (the pipelined chain walks its 2 KB pairs in chunks of TB_CH: registers for two chunks)
+template <int NE, int U0 = 0>
+__device__ __forceinline__ double tb_column_chain(double di, int P, int slot, int i, int sv, int pv, const double (&e)[NE], double rv,
                                                   bool cond)
 {
 #pragma unroll
-    for (int u = 0; u < TB_KMAX; ++u) {
+    for (int k = 0; k < NE; ++k) {
+        const int u = U0 + k;
         if (u < P) {
             const int pu = __builtin_amdgcn_readlane(pv, u);
-            if (slot == __builtin_amdgcn_readlane(sv, u)) di = cond ? e[u] : ((i == pu) ? 1.0 : 0.0);
-            else di = fma(e[u], tf_readlane_f64(rv, u), (i == pu) ? -0.0 : di);
+            if (slot == __builtin_amdgcn_readlane(sv, u)) di = cond ? e[k] : ((i == pu) ? 1.0 : 0.0);
+            else di = fma(e[k], tf_readlane_f64(rv, u), (i == pu) ? -0.0 : di);
         }
     }
     return di;
 }
+#define TB_CH 16
+// buf[k] = base[(U0 + k) * stride] for the updates below P; `on`: this lane has an element
+template <int U0>
+__device__ __forceinline__ void tb_ld_chunk(double (&buf)[TB_CH], const double *base, int64_t stride, int P, bool on)
+{
+#pragma unroll
+    for (int k = 0; k < TB_CH; ++k) buf[k] = (U0 + k < P && on) ? base[(U0 + k) * stride] : 0.0;
+}
+// loads issued after this point stay after it (the compiler would hoist a chunk's loads above the chain before it and
+// pay for the registers: two waves per SIMD instead of four)
+#define TB_LOADS_STAY_BELOW() asm volatile("" ::: "memory")
 
 // entering decision, column of the tableau as the u pending updates leave it, ratio-test partials
-template <int MODE>
+template <int MODE, bool OLD = false>
 __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 {
     __shared__ TbCand sh_price[TB_THREADS / 64];
@@ -192,12 +221,21 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
     const int l32 = tid & 31;
     const int pv = (MODE != TB_SELECT && l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2; // rows and slots < 2^31 (or -1)
     const int sv = (MODE != TB_SELECT && l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
-    double e[TB_KMAX];
-    if (MODE != TB_SELECT) {
-        const double *Eti = a.b.Et + (inm ? i : 0); // coalesced over the rows of the workgroup
+    // the block whose pass is in flight (pipelined chain): its pairs are complete
+    const int PO = OLD ? a.uo : 0;
+    double e[OLD ? 1 : TB_KMAX];
+    double ea[OLD ? TB_CH : 1], eb[OLD ? TB_CH : 1]; // OLD: the 2 KB multipliers of a row pass through two chunks of registers
+    const double *Eti = a.b.Et + (inm ? i : 0); // coalesced over the rows of the workgroup
+    const double *Eto = OLD ? a.o.Et + (inm ? i : 0) : nullptr;
+    if constexpr (OLD) {
+        tb_ld_chunk<0>(ea, Eto, a.o.lde, PO, true);
+        tb_ld_chunk<TB_CH>(eb, Eto, a.o.lde, PO, true);
+    } else if (MODE != TB_SELECT) {
 #pragma unroll
         for (int u = 0; u < TB_KMAX; ++u) e[u] = (u < P) ? Eti[u * a.b.lde] : 0.0;
     }
+    const int pvo = (OLD && l32 < PO) ? ((const int *)a.o.prow)[2 * l32] : -2;
+    const int svo = (OLD && l32 < PO) ? ((const int *)a.o.pslot)[2 * l32] : -2;
     // entering variable (primal_solvers.py:135-142) and its column slot; the scan of the pricing partials goes out with the
     // other loads (valid addresses whatever the status)
     TbCand c{LPX_INF, LPX_NOIDX, -1};
@@ -268,8 +306,20 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         }
     } else {
         const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0; // lane l: entry `slot` of pivot row l
+        const double rvo = (OLD && l32 < PO) ? a.o.R[l32 * a.o.ldr + slot] : 0.0;
         di = inm ? s.T[i * s.ld + slot] : 0.0;
-        di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
+        if constexpr (OLD) {
+            di = tb_column_chain<TB_CH, 0>(di, PO, (int)slot, (int)i, svo, pvo, ea, rvo, cond);
+            TB_LOADS_STAY_BELOW();
+            tb_ld_chunk<0>(ea, Eti, a.b.lde, P, true);
+            di = tb_column_chain<TB_CH, TB_CH>(di, PO, (int)slot, (int)i, svo, pvo, eb, rvo, cond);
+            TB_LOADS_STAY_BELOW();
+            tb_ld_chunk<TB_CH>(eb, Eti, a.b.lde, P, true);
+            di = tb_column_chain<TB_CH, 0>(di, P, (int)slot, (int)i, sv, pv, ea, rv, cond);
+            di = tb_column_chain<TB_CH, TB_CH>(di, P, (int)slot, (int)i, sv, pv, eb, rv, cond);
+        } else {
+            di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
+        }
         if (inm) a.d[i] = di; // d[m] = the entering variable's reduced cost
     }
     // ratio test (primal_solvers.py:149-167): first minimum over this workgroup's rows, with what the winner needs
@@ -291,6 +341,25 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
 
 // leaving row, eta column, x_B, the pivot row as the pending updates leave it, the reduced-cost row and its pricing
 // partials, bookkeeping
+// row r of the tableau through the P pending updates of one block: lane l of every wave holds update l's pivot row (pv),
+// rewritten column (sv) and multiplier of row r (erv); ru[u] = R[u][g]
+template <int NE, int U0 = 0>
+__device__ __forceinline__ double tb_row_chain(double rowp, int P, int r, int g, int pv, int sv, double erv, const double (&ru)[NE], bool cond)
+{
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int u = U0 + k;
+        if (u < P) {
+            const double er = tf_readlane_f64(erv, u);
+            const bool isr = r == __builtin_amdgcn_readlane(pv, u); // wave-uniform
+            const double v = isr ? er * ru[k] : fma(er, ru[k], rowp);
+            rowp = (g == __builtin_amdgcn_readlane(sv, u)) ? (cond ? er : (isr ? 1.0 : 0.0)) : v;
+        }
+    }
+    return rowp;
+}
+
+template <bool OLD = false>
 __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
 {
     __shared__ TbCand sh_price[TB_THREADS / 64];
@@ -307,9 +376,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int64_t j = ctrl->enter_j;
     const int64_t slot = (int64_t)a.b.scal[0];
     const bool incol = g < ncopy;
-    double ru[TB_KMAX];
+    const int PO = OLD ? a.uo : 0; // the block whose pass is in flight (pipelined chain)
+    double ru[OLD ? 1 : TB_KMAX];
+    double ra[OLD ? TB_CH : 1], rb[OLD ? TB_CH : 1]; // OLD: the 2 KB pivot-row entries of a column pass through two chunks
+    const double *Rg = a.b.R + (incol ? g : 0), *Rog = OLD ? a.o.R + (incol ? g : 0) : nullptr;
+    if constexpr (OLD) {
+        tb_ld_chunk<0>(ra, Rog, a.o.ldr, PO, incol);
+        tb_ld_chunk<TB_CH>(rb, Rog, a.o.ldr, PO, incol);
+    } else {
 #pragma unroll
-    for (int u = 0; u < TB_KMAX; ++u) ru[u] = (u < P && incol) ? a.b.R[u * a.b.ldr + g] : 0.0;
+        for (int u = 0; u < TB_KMAX; ++u) ru[u] = (u < P && incol) ? a.b.R[u * a.b.ldr + g] : 0.0;
+    }
     const double rc_old = (g < n) ? a.b.rc[g] : 0.0;
     const double dg = (g <= m) ? a.d[g] : 0.0, dm = a.d[m];
     const double xg = (g < m) ? a.b.xb[g] : 0.0;
@@ -317,6 +394,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     const int l32 = tid & 31; // lane l holds pending update l's pivot row / rewritten column / multiplier of row r
     const int pv = (l32 < P) ? ((const int *)a.b.prow)[2 * l32] : -2;
     const int sv = (l32 < P) ? ((const int *)a.b.pslot)[2 * l32] : -2;
+    const int pvo = (OLD && l32 < PO) ? ((const int *)a.o.prow)[2 * l32] : -2;
+    const int svo = (OLD && l32 < PO) ? ((const int *)a.o.pslot)[2 * l32] : -2;
     const int64_t pivots0 = ctrl->pivots; // used by the bookkeeping thread only
     // the ratio partials too (their addresses are valid whatever the status): leaving row = first minimum ratio over the
     // workgroups' partials (primal_solvers.py:166, np.argmin), each with its payload
@@ -356,15 +435,19 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
     double rowp = 0.0;
     {
         const double erv = (l32 < P) ? a.b.E[r * TB_KMAX + l32] : 0.0;
+        const double ervo = (OLD && l32 < PO) ? a.o.E[r * TB_KMAX + l32] : 0.0;
         rowp = incol ? s.T[r * s.ld + g] : 0.0;
-#pragma unroll
-        for (int u = 0; u < TB_KMAX; ++u) {
-            if (u < P) {
-                const double er = tf_readlane_f64(erv, u);
-                const bool isr = (int)r == __builtin_amdgcn_readlane(pv, u); // wave-uniform
-                const double v = isr ? er * ru[u] : fma(er, ru[u], rowp);
-                rowp = ((int)g == __builtin_amdgcn_readlane(sv, u)) ? (cond ? er : (isr ? 1.0 : 0.0)) : v;
-            }
+        if constexpr (OLD) {
+            rowp = tb_row_chain<TB_CH, 0>(rowp, PO, (int)r, (int)g, pvo, svo, ervo, ra, cond);
+            TB_LOADS_STAY_BELOW();
+            tb_ld_chunk<0>(ra, Rg, a.b.ldr, P, incol);
+            rowp = tb_row_chain<TB_CH, TB_CH>(rowp, PO, (int)r, (int)g, pvo, svo, ervo, rb, cond);
+            TB_LOADS_STAY_BELOW();
+            tb_ld_chunk<TB_CH>(rb, Rg, a.b.ldr, P, incol);
+            rowp = tb_row_chain<TB_CH, 0>(rowp, P, (int)r, (int)g, pv, sv, erv, ra, cond);
+            rowp = tb_row_chain<TB_CH, TB_CH>(rowp, P, (int)r, (int)g, pv, sv, erv, rb, cond);
+        } else {
+            rowp = tb_row_chain(rowp, P, (int)r, (int)g, pv, sv, erv, ru, cond);
         }
         if (incol) a.b.R[P * a.b.ldr + g] = rowp;
     }
@@ -421,6 +504,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         a.b.pslot[P] = slot;
         a.b.rowflag[r] |= 1u << P;
         *a.b.cnt = P + 1;
+        a.b.tsel[0] = a.dstid; // where the tableau lives once this block's pass has run (0 unless the chain is pipelined)
 #ifdef LPX_TB_STAMPS
         g_tb_stamp[1][8] = (long long)wall_clock64();
         if (ctrl->pivots >= 96 && ctrl->pivots < 160 && (P == 0 || P == 15 || P == 31)) {

@@ -19,11 +19,14 @@ struct TbWs {
     int64_t *cnt;      // pending updates
     double *scal;      // [0] column slot of the entering variable of the pivot in flight
     double *dbest, *xbest; // ratio partials' payload: entering-column entry and x_B of the partial's argmin row
+    int64_t *tsel;     // pipelined chain: [0] = buffer that holds the tableau once the passes of the pivots done so far have run
+                       // (0: T, 1: T_alt); written with every pivot, read by the call's closing copy-back
 };
 
 // the pass over the tableau (lpx_tb_flush.hpp, compiled in lpx_tb_flush.hip)
 struct TbFlushArgs {
-    double *T;
+    const double *T;        // source
+    double *Tdst;           // destination: T itself (in place) or the other buffer of the pipelined chain
     int64_t rows, cols, ld; // cols = n + 1 (column n is x_B); ld even
     int cond;               // condensed layout: a rewritten column receives the eta column, else a unit vector
     const double *E;        // rows x TB_KMAX

@@ -147,7 +147,7 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
             if (live[v]) {
 #pragma unroll
                 for (int q = 0; q < RG; ++q)
-                    if (i0 + q < row1) lpx_st2<NT>(a.T + (i0 + q) * ld + col[v], d2_t{x[q][2 * v], x[q][2 * v + 1]});
+                    if (i0 + q < row1) lpx_st2<NT>(a.Tdst + (i0 + q) * ld + col[v], d2_t{x[q][2 * v], x[q][2 * v + 1]});
             }
         }
     }

@@ -105,6 +105,10 @@ class TableauEngine:
     LOOKAHEAD = os.environ.get("LPX_TABLEAU_LOOKAHEAD", "1") != "0"
     #: largest tableau (bytes) that gets the second buffer of the single-launch chain
     FUSED_MAX_BYTES = int(os.environ.get("LPX_TABLEAU_FUSED_MAX_MB", "256")) << 20
+    #: smallest tableau (bytes) that gets a second buffer for the pipelined deferred-update chain (lpx.h,
+    #: lpx_tableau_pipelined: the pass over the tableau and the next block's decisions run side by side); negative = never
+    PIPELINE_MIN_BYTES = (None if int(os.environ.get("LPX_TABLEAU_PIPELINE_MIN_MB", "1024")) < 0
+                          else int(os.environ.get("LPX_TABLEAU_PIPELINE_MIN_MB", "1024")) << 20)
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
                  group=None, pricing="first_negative", dual=False, slot_var=None, var_slot=None):
@@ -145,6 +149,9 @@ class TableauEngine:
         # HBM-bound, the three-kernel in-place chain costs nothing and the memory is better left alone
         self.T_alt = None
         if group is None and T.numel() * 8 <= self.FUSED_MAX_BYTES:
+            self.T_alt = torch.zeros_like(T)
+        elif (group is None and not self.dual and self.PIPELINE_MIN_BYTES is not None
+              and 8 * (self.m + 1) * (self.n + 1) >= self.PIPELINE_MIN_BYTES):
             self.T_alt = torch.zeros_like(T)
         s.T_alt = None if self.T_alt is None else self.T_alt.data_ptr()
         _lib.check(self.lib.lpx_ctrl_init(s.ctrl, int(f32_phase), stream_ptr()))
@@ -318,6 +325,9 @@ class TableauEngine:
         # every call starts by re-reading the reduced-cost row and x_B from T and ends with a pass over T
         kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
         chunk, first_chunk = (8 * kb, kb) if kb > 0 else (self.CHUNK, self.FIRST_CHUNK)
+        if kb > 0 and self.group is None and not self.dual and self.lib.lpx_tableau_pipelined(C.byref(self.s)):
+            # pipelined chain: the first and the last block of a call overlap with nothing, so calls are long
+            chunk, first_chunk = 32 * kb, 2 * kb
         while left > 0:
             # short first chunk (eager launches): small solves end here; later chunks are long enough for
             # liblpx to replay them as hipGraphs
