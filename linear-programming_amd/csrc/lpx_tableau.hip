@@ -1364,6 +1364,8 @@ static inline int t_block_size(const lpx_tableau *s)
     // 0.96 / - / 17.8: the chain pays ~15 us of decision kernels per pivot whatever the size
     const int64_t bytes = 8 * (s->m + 1) * (s->n + 1);
     if (bytes < ((int64_t)lpx_env_int("LPX_TABLEAU_BLOCK_MIN_MB", 48) << 20)) return 0;
+    // one partial record per workgroup of TB_THREADS rows / columns
+    if (lpx_cdiv(s->n, TB_THREADS) > LPX_MAXP || lpx_cdiv(s->m + 2, TB_THREADS) > LPX_MAXP) return 0;
     const int kb = lpx_env_int("LPX_TABLEAU_BLOCK", bytes >= ((int64_t)192 << 20) ? 32 : 16);
     return (kb == 8 || kb == 16 || kb == 32) ? kb : 0;
 }
@@ -1543,6 +1545,7 @@ static int tableau_iterate_pipelined(const lpx_tableau *s, const TabWs &w, int64
     const int64_t nprep = lpx_cdiv(t_prep_len(s), TB_THREADS);
     const int64_t nb = lpx_cdiv(iters, KB);
     double *buf[2] = {s->T, s->T_alt};
+    const bool serial = lpx_env_int("LPX_TB_PIPE_SERIAL", 0) != 0; // diagnostic: same kernels and streams, nothing side by side
     LPX_HIP(hipEventRecord(pp->fork, st));
     LPX_HIP(hipStreamWaitEvent(sd, pp->fork, 0));
     if (sf != st) LPX_HIP(hipStreamWaitEvent(sf, pp->fork, 0));
@@ -1561,6 +1564,7 @@ static int tableau_iterate_pipelined(const lpx_tableau *s, const TabWs &w, int64
         a.dstid = dstid;
         if (k > 0) a.s.T = buf[(k - 1) & 1]; // the source of the pass in flight
         if (k >= 2) LPX_HIP(hipStreamWaitEvent(sd, pp->evF[(k - 2) & 3], 0));
+        if (k >= 1 && serial) LPX_HIP(hipStreamWaitEvent(sd, pp->evF[(k - 1) & 3], 0));
         int64_t it = 0;
         const bool old = k > 0;
         auto one = [&](hipStream_t q) {

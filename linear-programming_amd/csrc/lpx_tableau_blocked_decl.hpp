@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 #define TB_KMAX 32 /* largest block; E rows are TB_KMAX doubles apart whatever the block size in use */
-#define TB_THREADS 256
+#define TB_THREADS 128 /* per-pivot kernels: 128-thread workgroups spread evenly over the CUs the pipelined chain leaves them */
 
 struct TbWs {
     double *E;         // (m + 2) x TB_KMAX: E[i][u] = eta column of pending update u, row i (the pass over T reads rows)

@@ -36,6 +36,11 @@ for s, e, k in dec:
         pi += 1
     if pi < len(passes) and passes[pi][0] <= s and e <= passes[pi][1]:
         inside += e - s
+# gaps between consecutive decision kernels (end -> next start), steady state
+gaps = [dec[k + 1][0] - dec[k][1] for k in range(len(dec) - 1)]
+gaps = sorted(g for g in gaps if 0 <= g < 50000)
+if gaps:
+    print(f"gap between consecutive decision kernels: median {gaps[len(gaps) // 2] / 1e3:.2f} us, mean {sum(gaps) / len(gaps) / 1e3:.2f} us, p90 {gaps[int(0.9 * len(gaps))] / 1e3:.2f} us")
 print(f"passes {len(passes)}, decision launches {len(dec)}, decision time inside a pass: {100.0 * inside / max(1, total):.1f} %")
 if len(passes) > 6:
     s0, e0 = passes[len(passes) // 2]
