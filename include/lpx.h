@@ -287,9 +287,11 @@ int lpx_tableau_commit_update(const lpx_tableau *s, void *stream);
  * its own slice.  Same exchange as lpx_tableau_propose / _commit (same message layout, primal_solvers.py:135-167), but
  * the proposal's column and the commit's pivot row are formed from the stale slice plus the `pending` (eta column,
  * pivot row) pairs of the current block, and no update kernel runs until lpx_tableau_block_flush applies the block
- * (`block` = lpx_tableau_block_size(): at most that many pivots between two flushes; flush before anything else reads T).
+ * (`block` = 8, 16 or 32: at most that many pivots between two flushes; flush before anything else reads T.  Every rank
+ * must run with the SAME block -- ranks that flush at different pivots stop exchanging at different pivots -- so the
+ * caller agrees on one value first: the largest lpx_tableau_block_size() over the ranks' ragged slices, TableauEngine.kb).
  *   lpx_tableau_block_begin                    once before the first propose of a run of pivots (after the caller touched T)
- *   lpx_tableau_block_propose(pending, send)   pending = pivots since the last flush (0 .. block-1)
+ *   lpx_tableau_block_propose(pending, send)   pending = pivots since the last flush (0 .. block-1; 32 and more: LPX_E_ARG)
  *   all-gather of the proposals                (caller: RCCL / torch.distributed)
  *   lpx_tableau_block_commit(pending, recv)    entering / leaving decision, eta column, bookkeeping: pending + 1 are now pending
  *   lpx_tableau_block_flush(block)             T <- T with the pending updates applied, in order */

@@ -1617,7 +1617,6 @@ extern "C" int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, 
     int rc = check_tableau(s);
     if (rc) return rc;
     LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
-    LPX_REQUIRE(t_block_size(s) == 0 || pending < t_block_size(s), "more pivots pending than lpx_tableau_block_size(): flush first");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
     a.u = (int)pending;
@@ -1632,7 +1631,6 @@ extern "C" int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, c
     if (rc) return rc;
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
-    LPX_REQUIRE(t_block_size(s) == 0 || pending < t_block_size(s), "more pivots pending than lpx_tableau_block_size(): flush first");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
     a.u = (int)pending;
@@ -1650,7 +1648,6 @@ extern "C" int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void
     int rc = check_tableau(s);
     if (rc) return rc;
     LPX_REQUIRE(block == 8 || block == 16 || block == 32, "block size must be 8, 16 or 32");
-    LPX_REQUIRE(t_block_size(s) == 0 || block >= t_block_size(s), "block smaller than lpx_tableau_block_size(): pending updates would be lost");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     tb_flush(s, w, (int)block, (hipStream_t)stream);
     LPX_LAUNCH_CHECK();
@@ -2208,7 +2205,6 @@ extern "C" int lpx_tableau_dual_block_propose(const lpx_tableau *s, int64_t pend
     int rc = check_tableau(s);
     if (rc) return rc;
     LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
-    LPX_REQUIRE(t_block_size(s) == 0 || pending < t_block_size(s), "more pivots pending than lpx_tableau_block_size(): flush first");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
     a.u = (int)pending;
@@ -2226,7 +2222,6 @@ extern "C" int lpx_tableau_dual_block_commit(const lpx_tableau *s, int64_t pendi
     if (rc) return rc;
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
-    LPX_REQUIRE(t_block_size(s) == 0 || pending < t_block_size(s), "more pivots pending than lpx_tableau_block_size(): flush first");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
     a.u = (int)pending;

@@ -158,9 +158,18 @@ class TableauEngine:
         # column partition
         self.group = group
         self.nranks = 1
+        #: pivots per pass over the tableau (0: one update per pivot).  Column-partitioned: ONE value for all ranks -- the
+        #: slices are ragged, so lpx_tableau_block_size() of a rank's own slice can differ across ranks at a size
+        #: threshold, and ranks that disagree issue different numbers of collectives (a hang): the largest wins
+        self.kb = int(self.lib.lpx_tableau_block_size(C.byref(s)))
         if group is not None:
             self.exchange = ProposalExchange(group, self.lib.lpx_tableau_msg_len(self.m), "cuda")
             self.nranks = self.exchange.nranks
+            import torch.distributed as dist
+
+            t = torch.tensor([self.kb], dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self.kb = int(t.item())
 
     # ------------------------------------------------------------------ construction from a host problem
     @classmethod
@@ -243,7 +252,7 @@ class TableauEngine:
         ex = self.exchange
         iters = int(iters)
         if self.dual:
-            kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
+            kb = self.kb
             if kb > 0 and iters > 0:  # large slices: deferred updates (lpx.h, lpx_tableau_dual_block_*)
                 _lib.check(self.lib.lpx_tableau_dual_block_begin(C.byref(self.s), st))
                 for it in range(iters):
@@ -277,7 +286,7 @@ class TableauEngine:
                 ex.wait(work)
                 cur = nxt
             return
-        kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
+        kb = self.kb
         if kb > 0 and iters > 0:
             # large slices: deferred updates (lpx.h, lpx_tableau_block_*): propose -> all-gather -> commit per pivot, one pass
             # over the slice per kb pivots; T is current again when the call returns
@@ -323,7 +332,7 @@ class TableauEngine:
         first = True
         # deferred updates (large tableaus): whole blocks between two looks at the control block, and more of them --
         # every call starts by re-reading the reduced-cost row and x_B from T and ends with a pass over T
-        kb = int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
+        kb = self.kb if self.group is not None else int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
         chunk, first_chunk = (8 * kb, kb) if kb > 0 else (self.CHUNK, self.FIRST_CHUNK)
         if kb > 0 and self.group is None and not self.dual and self.lib.lpx_tableau_pipelined(C.byref(self.s)):
             # pipelined chain: the first and the last block of a call overlap with nothing, so calls are long

@@ -329,8 +329,16 @@ def main():
         from linprog_amd.tableau import PrimalTableauSimplexSolver
 
         torch.cuda.set_device(0)
+        if os.environ.get("LPX_TEST_RAGGED_KB"):
+            # ranks whose own slices would pick DIFFERENT block sizes (a ragged partition at a size threshold): rank 0
+            # alone sees deferred updates on; the engine must settle on one value for all ranks
+            os.environ["LPX_TABLEAU_BLOCK_MIN_MB"] = "0" if rank == 0 else "1000000"
         cls = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": maxiters + 1})
         s = cls(c, A, b, basis, group=dist.group.WORLD)
+        if os.environ.get("LPX_TEST_RAGGED_KB"):
+            kbs = [None] * world
+            dist.all_gather_object(kbs, s._engine.kb)
+            assert len(set(kbs)) == 1 and kbs[0] == int(os.environ["LPX_TABLEAU_BLOCK"]), f"ranks disagree on the block: {kbs}"
         res = s.solve(maxiters)
         assert s.pivot_log().tolist() == want.log.tolist(), f"rank {rank}: pivot sequence differs"
         assert res.basis.tolist() == want.basis.tolist() and res.optimum == (want.status == O.OPTIMAL)

@@ -318,9 +318,41 @@ def bounded_cases():
     return out
 
 
+PHASE_ONE_PROBLEMS = [
+    # small-integer LPs with redundant (duplicated / summed) equations: an artificial variable stays basic at level zero
+    # after phase one and is pivoted out or its row dropped (special_solvers.py:61-89); every pivot is exact
+    ([[1, 0, 0, 1, 0, 0], [0, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 1], [1, 1, 0, 1, 1, 0]], [2, 3, 1, 5]),
+    ([[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]], [2, 2, 3]),
+    ([[1, 2, 1, 0, 0], [2, 4, 2, 0, 0], [0, 1, 0, 1, 0], [1, 0, 0, 0, 1]], [4, 8, 3, 2]),
+    ([[1, 1, 1, 0], [1, -1, 0, 1], [2, 0, 1, 1]], [4, 0, 4]),
+    ([[1, 0, 1, 0, 2], [0, 1, 0, 1, 1], [1, 1, 1, 1, 3], [2, 1, 2, 1, 5]], [3, 2, 5, 8]),
+    ([[2, 1, 0, 1], [4, 2, 0, 2], [0, 1, 1, 0]], [6, 12, 2]),
+]
+
+
+def phase_one_cases():
+    """PhaseOneSimplexSolver (special_solvers.py:11-91) on LPs with redundant rows: the basis handed to phase two, the
+    rows kept (A, b after the drop) and every pivot incl. the drive-out pivots."""
+    out = []
+    for A, b in PHASE_ONE_PROBLEMS:
+        A, b = np.array(A, dtype=float), np.array(b, dtype=float)
+        with Trace() as tr:
+            p1 = special_solvers.PhaseOneSimplexSolver(np.zeros(A.shape[1]), A.copy(), b.copy())
+            try:
+                p1.solve(1000)
+                exc = None
+            except Exception as e:
+                exc = type(e).__name__
+        out.append(dict(problem="phase_one_redundant", solver="PhaseOneSimplexSolver", A=A.tolist(), b=b.tolist(),
+                        ref=dict(pivots=tr.events, exception=exc, basis=[int(v) for v in p1.basis], m=int(p1.m),
+                                 A=np.asarray(p1.A, dtype=float).tolist(), b=np.asarray(p1.b, dtype=float).tolist())))
+        print(f"  phase one {A.shape}: basis {out[-1]['ref']['basis']}, rows kept {p1.m}, exc={exc}", flush=True)
+    return out
+
+
 def primal_dual_cases():
     out = []
-    for m in (4, 8, 16, 32, 64):  # 64: the size bench.py --workload config5 times
+    for m in (4, 8, 16, 32, 64, 128):  # 64: the size bench.py --workload config5 times; 128: beyond the one-launch kernel
         for seed in range(2):
             t0 = time.time()
             c, A, b, _ = gen.gen_dual(m, 2 * m, seed)
@@ -356,6 +388,7 @@ def main():
     dump("diet.json", lambda: [diet_case()])
     dump("bounded.json", bounded_cases)
     dump("primal_dual.json", primal_dual_cases)
+    dump("phase_one.json", phase_one_cases)
     dump("random.json", lambda: random_cases(False))
     dump("degenerate.json", degenerate_cases)
     if args.large:

@@ -72,6 +72,14 @@ def test_product_path_deferred_updates(nproc, m, n, env):
     _run("gpu", nproc, m, n, 2, 100000, LPX_TABLEAU_BLOCK_MIN_MB="0", **env)
 
 
+@pytest.mark.gpu
+def test_product_path_ranks_agree_on_one_block_size():
+    """Ragged slices at a size threshold: lpx_tableau_block_size() of the ranks' own slices differs (here forced: rank 0
+    alone gets deferred updates).  Every rank must run with the same block -- else they flush and stop at different pivots
+    and the collective counts diverge (a hang) -- so the engine all-reduces it (tableau.py: TableauEngine.kb)."""
+    _run("gpu", 3, 50, 121, 2, 100000, LPX_TEST_RAGGED_KB="1", LPX_TABLEAU_BLOCK="16")
+
+
 @pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
 def test_dual_protocol_cpu_gloo(nproc, m, n):
     _run("cpu-dual", nproc, m, n, 1, 100000)

@@ -67,6 +67,41 @@ def test_config4_tableau_invariants():
     assert o.log.tolist() == log[:kc].tolist()
 
 
+def test_config4_headline_path_bit_exact_vs_oracle():
+    """The instances that carry the headline, at the headline's size: one solve(96) -- three full blocks of 32 through the
+    PIPELINED chain (decision kernels with the previous block's pairs in their chains, the pass in its hot instance
+    k_tb_flush2<32, nt, 8, 256, 1, 1> writing the other buffer, the last one in place) -- then a ragged solve(40) (a full
+    block and a short one: the twin instance).  The WHOLE pivot log against the 16-thread oracle (condensed layout), and
+    the WHOLE tableau -- every carried column, x_B, the reduced-cost row -- bit for bit against the oracle's."""
+    import ctypes as C
+
+    from linprog_amd import _lib
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    m, n = 20000, 40000
+    A, b, c, basis = gen.gen_primal_columns(m, n, 0, 0, n)
+    cls = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": 256})
+    s = cls(c, A, b, basis, columns=(0, n), n_global=n)
+    eng = s._engine
+    lib = _lib.load()
+    assert eng.slot_var is not None and lib.lpx_tableau_block_size(C.byref(eng.s)) == 32
+    assert lib.lpx_tableau_pipelined(C.byref(eng.s)) == 1 and eng.T_alt is not None
+    o = O.OracleTableau(c, A, b, basis, log_cap=256, threads=16, condensed=True)
+    w = o.nslots + 1
+    for k in (96, 40):
+        res = s.solve(k)
+        r = o.solve(k)
+        assert res.iters == k == r.iters and res.optimum is False
+        log = s.pivot_log()
+        assert log.tolist() == o.log[:len(log)].tolist()
+        assert np.array_equal(eng.slot_var.cpu().numpy(), o.slot_var) and res.basis.tolist() == r.basis.tolist()
+        for r0 in range(0, m + 1, 4000):  # by row blocks: bounded temporaries
+            assert np.array_equal(eng.T[r0:r0 + 4000, :w].cpu().numpy(), o.T[r0:r0 + 4000, :w]), f"rows {r0}.."
+        assert np.array_equal(res.x, r.x)
+    assert len(s.pivot_log()) == 136
+
+
 @pytest.mark.parametrize("form", ["tableau", "revised"])
 def test_config3_batch_full_size(form):
     from linprog_amd.batched import BatchedPrimalSolver, BatchedTableauSolver

@@ -270,19 +270,16 @@ def test_tableau_row_entry_point_and_artificial_drive_out():
     for row in (0, 17, 39):
         got = s._engine.tableau_row(row)
         assert np.allclose(got, T[row], rtol=1e-12, atol=1e-12)
-    # redundant equations with small integer data (every pivot exact): expected bases and kept rows are the reference's
-    # PhaseOneSimplexSolver on the same inputs (run in the build container)
-    cases = [
-        ([[1, 0, 0, 1, 0, 0], [0, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 1], [1, 1, 0, 1, 1, 0]], [2, 3, 1, 5], [0, 1, 2], 3),
-        ([[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]], [2, 2, 3], [0, 2], 2),
-        ([[1, 2, 1, 0, 0], [2, 4, 2, 0, 0], [0, 1, 0, 1, 0], [1, 0, 0, 0, 1]], [4, 8, 3, 2], [1, 3, 0], 3),
-        ([[1, 1, 1, 0], [1, -1, 0, 1], [2, 0, 1, 1]], [4, 0, 4], [1, 0], 2),
-    ]
-    for A, b, want_basis, want_m in cases:
-        A, b = np.array(A, dtype=float), np.array(b, dtype=float)
+    # redundant equations with small integer data (every pivot exact): bases, kept rows and right-hand sides are the
+    # reference's PhaseOneSimplexSolver on the same inputs (tests/golden/phase_one.json, make_golden.py::phase_one_cases)
+    cases = load("phase_one.json")
+    assert len(cases) >= 6
+    for cs in cases:
+        A, b, ref = np.array(cs["A"], dtype=float), np.array(cs["b"], dtype=float), cs["ref"]
         p1 = PhaseOneSimplexSolver(np.zeros(A.shape[1]), A, b)
         p1.solve(1000)
-        assert p1.basis.tolist() == want_basis and int(p1.m) == want_m and p1.A.shape[0] == want_m
+        assert p1.basis.tolist() == ref["basis"] and int(p1.m) == ref["m"]
+        assert np.array_equal(np.asarray(p1.A, dtype=float), np.array(ref["A"])) and np.array_equal(np.asarray(p1.b, dtype=float), np.array(ref["b"]))
 
 
 def test_standard_form_on_device_equals_the_host_helpers():

@@ -194,8 +194,10 @@ def test_deferred_chain_dantzig_opt_in_matches_oracle(m, n, seed, pipe, monkeypa
     assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
 
 
-def test_block_entry_points_reject_more_pending_updates_than_the_block(monkeypatch):
-    """lpx_tableau_block_propose / _commit / _flush refuse a pending count or a block size that would lose updates."""
+def test_block_entry_points_reject_more_pending_updates_than_the_largest_block(monkeypatch):
+    """lpx_tableau_block_propose / _commit refuse a pending count beyond the largest block (32), _flush a block size it has no
+    instance for.  The block itself is the caller's to agree on (column-partitioned: one value for all ranks, which may be
+    larger than lpx_tableau_block_size() of a rank's own ragged slice -- ADVICE round 2)."""
     import ctypes as C
 
     from linprog_amd import _lib
@@ -205,10 +207,9 @@ def test_block_entry_points_reject_more_pending_updates_than_the_block(monkeypat
     c, A, b, basis = gen.gen_primal(40, 90, 1)
     eng = PrimalTableauSimplexSolver(c, A, b, basis)._engine
     lib = _lib.load()
-    assert lib.lpx_tableau_block_size(C.byref(eng.s)) == 8
+    assert lib.lpx_tableau_block_size(C.byref(eng.s)) == 8 and eng.kb == 8
     buf = eng.torch.zeros(int(lib.lpx_tableau_msg_len(eng.m)), dtype=eng.torch.float64, device="cuda")
-    assert lib.lpx_tableau_block_propose(C.byref(eng.s), 8, buf.data_ptr(), None) == -1
-    assert lib.lpx_tableau_block_commit(C.byref(eng.s), 9, buf.data_ptr(), 1, None) == -1
-    monkeypatch.setenv("LPX_TABLEAU_BLOCK", "16")
-    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 8, None) == -1
-    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 16, None) == 0
+    assert lib.lpx_tableau_block_propose(C.byref(eng.s), 32, buf.data_ptr(), None) == -1
+    assert lib.lpx_tableau_block_commit(C.byref(eng.s), 33, buf.data_ptr(), 1, None) == -1
+    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 12, None) == -1
+    assert lib.lpx_tableau_block_flush(C.byref(eng.s), 16, None) == 0  # a larger block than this slice's own default
