@@ -75,6 +75,7 @@ def main():
     import torch.distributed as dist
 
     import linprog_amd  # noqa: F401
+    from linprog_amd import _lib as _lpx
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,6 +88,7 @@ def main():
     if os.environ.get("LPX_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    _lpx.selfcheck()  # every kernel instance of liblpx resolves on this device (an error, not an abort, if one does not)
     group = None
     # LPX_BENCH_FORCE_DIST=1: also build the process group at world size 1 (a one-GPU box can then run the RCCL
     # collectives of the partitioned path with a single rank)
@@ -144,7 +146,9 @@ def main():
     finish(out)
 
 
-FP64_FMA_PEAK = 78.6e12 / 2  # MI355X_MICROARCH.md: 78.6 TFLOP/s vector fp64 = 39.3 T fma/s
+# AMD's published MI355X figure, 78.6 TFLOP/s vector fp64 = 39.3 T fma/s (MI355X_MICROARCH.md has no fp64 row; on random
+# operands the chip sustains 26-28 T fma/s: tools/fma_rate.hip)
+FP64_FMA_PEAK = 78.6e12 / 2
 
 
 def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
@@ -169,6 +173,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     A_cols, b, c, basis = problems.gen_primal_columns(m, n, args.seed, j0, j1)
     PPS = 32 if blocks else 1  # pivots per step
     Solver = type("BenchTableau", (PrimalTableauSimplexSolver,), {"_LOG_CAP": PPS * (W + 2 * K) + 8})
+    SUSTAIN_S = float(os.environ.get("LPX_BENCH_SUSTAINED_S", "2.0")) if blocks else 0.0
     solver = Solver(c, A_cols, b, basis, group=group, columns=(j0, j1), n_global=n)
     eng = solver._engine
     lib = _lib.load()
@@ -177,6 +182,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     kb = int(lib.lpx_tableau_block_size(C.byref(eng.s)))  # pivots per pass over T (this rank's slice), 0: one update per pivot
     if blocks and kb not in (0, PPS):
         PPS = kb
+    pipelined = bool(kb) and group is None and bool(lib.lpx_tableau_pipelined(C.byref(eng.s)))
     one_launch = kb == 0 and eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
     K_piv, W_piv = K * PPS, W * PPS
 
@@ -212,10 +218,32 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     k1_ms, k1_n = C.c_double(), C.c_int64()
     _lib.check(lib.lpx_profile_k1_read(C.byref(k1_ms), C.byref(k1_n)))
     _lib.check(lib.lpx_profile_k1(0))
+    # a second, LONG window (>= SUSTAIN_S seconds of the same loop, same state carried on): the K-step window above is a
+    # few tens of milliseconds
+    sustained = None
+    if SUSTAIN_S > 0 and group is None:
+        S_piv = max(PPS, int(SUSTAIN_S * K_piv / dt) // PPS * PPS)
+        barrier()
+        t1 = time.perf_counter()
+        eng.enqueue(S_piv)
+        barrier()
+        ds = time.perf_counter() - t1
+        extra += S_piv
+        sustained = {"value": S_piv / ds, "unit": "pivots/s", "seconds": ds, "pivots": S_piv, "steps": S_piv // PPS,
+                     "ms_per_step": ds / (S_piv // PPS) * 1e3,
+                     "gate": "same run, state carried on from the timed window: pivot count and RUNNING status checked, the "
+                             "log's prefix against the oracle (cpu_baseline.parity), x_B >= 0 and the cost below the timed "
+                             "window's afterwards"}
     ctrl = eng.read_ctrl()
     pivots_done = int(ctrl.pivots)
     if pivots_done != W_piv + K_piv + extra or ctrl.status != _lib.RUNNING:
         sys.exit(f"bench invalid: {pivots_done} pivots done of {W_piv + K_piv + extra}, status {ctrl.status}")
+    if sustained is not None:
+        xb_min = float(eng.T[:m, eng.n].min().item())
+        if xb_min < 0.0:
+            sys.exit(f"bench invalid: x_B went negative in the sustained window ({xb_min})")
+        sustained["min_xB"] = xb_min
+        sustained["objective"] = -float(eng.T[m, eng.n].item())
 
     # roofline of the update kernel on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
     n_loc = j1 - j0
@@ -256,6 +284,10 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
                             f"plus the pending (eta column, pivot row) pairs, then ONE kernel applies the {PPS} rank-1 updates "
                             f"to every element in order (deferred updates, bit-identical to one update per pivot)") if kb
                    else (f"{PPS} pivots, one rank-1 update of the whole tableau each" if PPS > 1 else "one pivot"),
+                   "chain": ("pipelined: the pass of block k streams T -> T_alt (and back) on the CUs of one stream while block "
+                             "k+1 is decided on the CUs of another from the buffer the pass reads plus the pending pairs of "
+                             "both blocks (chains of up to 64)") if pipelined
+                   else ("in place: decisions, then the pass" if kb else "one update per pivot"),
                    "pivots_per_step": PPS, "pivots_timed": K_piv, "us_per_pivot": dt / K_piv * 1e6,
                    "launches_per_pivot": ((2 if group is None else 3) + 1.0 / kb) if kb else (1 if one_launch else 3),
                    "partition": f"columns/{world}",
@@ -270,6 +302,8 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
                      else "HIP events in a separate eager pass (timed region replays hipGraphs)",
                      "whole_pivot_GBs": 16.0 * (m + 1) * (ncarry + 1) * K_piv / dt / 1e9},
     }
+    if sustained is not None:
+        out["sustained"] = sustained
     if kb:
         r = out["roofline"]
         del r["whole_pivot_GBs"]
@@ -578,7 +612,9 @@ def bench_config5(args):
     emit(out)
 
 
-FP64_FMA_PEAK = 78.6e12 / 2  # MI355X_MICROARCH.md: 78.6 TFLOP/s vector fp64 = 39.3 T fma/s
+# AMD's published MI355X figure, 78.6 TFLOP/s vector fp64 = 39.3 T fma/s (MI355X_MICROARCH.md has no fp64 row; on random
+# operands the chip sustains 26-28 T fma/s: tools/fma_rate.hip)
+FP64_FMA_PEAK = 78.6e12 / 2
 
 
 def bench_batch(args, rank, world, group, K, W):

@@ -143,6 +143,12 @@ typedef struct lpx_tableau {
 /* ---------------------------------------------------------------------------------------------- misc */
 int lpx_version(void);
 const char *lpx_last_error(void);
+/* Resolve every kernel instance the library's launchers can reach (hipFuncGetAttributes on each kernel handle; the list
+ * is generated at build time from the host stubs of the library's objects) and check that the current device is gfx950.
+ * LPX_OK, or LPX_E_HIP with lpx_last_error() naming the kernel -- instead of an abort inside its first launch.  No
+ * counterpart in the reference; run it once per process before trusting a new build (smoke(), bench.py and
+ * `LPX_SELFCHECK=1` imports do).  *kernels_checked (may be NULL) receives the number resolved. */
+int lpx_selfcheck(int64_t *kernels_checked);
 /* Zero a control block and set f32_phase (solver construction: primal_solvers.py:37-40). */
 int lpx_ctrl_init(lpx_ctrl *dev_ctrl, int32_t f32_phase, void *stream);
 /* Start of a solve() call: counter = 0, status = RUNNING (primal_solvers.py:189-190, dual_solvers.py:95). */

@@ -60,6 +60,7 @@ class LpxTableau(C.Structure):
 _SIGS = {
     "lpx_version": (C.c_int, []),
     "lpx_last_error": (C.c_char_p, []),
+    "lpx_selfcheck": (C.c_int, [C.POINTER(i64)]),
     "lpx_ctrl_init": (C.c_int, [vp, C.c_int32, vp]),
     "lpx_ctrl_begin_solve": (C.c_int, [vp, vp]),
     "lpx_read_ctrl": (C.c_int, [vp, C.POINTER(LpxCtrl), vp]),
@@ -157,7 +158,17 @@ def load():
             f.restype = res
             f.argtypes = args
         _lib = L
+        if os.environ.get("LPX_SELFCHECK") == "1":
+            selfcheck()
     return _lib
+
+
+def selfcheck():
+    """Resolve every kernel of liblpx on the current device (lpx.h, lpx_selfcheck); returns the number resolved, raises
+    LpxBackendError naming the first kernel without device code."""
+    n = i64(0)
+    check(load().lpx_selfcheck(C.byref(n)))
+    return int(n.value)
 
 
 def check(rc):

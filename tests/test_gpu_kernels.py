@@ -259,3 +259,13 @@ def test_graph_capture_failure_unwinds_and_the_next_call_works(env, monkeypatch)
     assert int(eng.read_ctrl().pivots) == total
     want.solve(total)
     assert s.pivot_log().tolist() == want.log[:total].tolist()
+
+
+def test_selfcheck_resolves_every_kernel_instance():
+    """lpx_selfcheck: every kernel handle of liblpx.so resolves to device code on this GPU (hipFuncGetAttributes); the list
+    is the library's own (generated from the host stubs of its objects), so it cannot drift from the launchers."""
+    from linprog_amd import _lib
+
+    n = _lib.selfcheck()
+    assert n >= 250, n
+    assert _lib.selfcheck() == n  # repeatable, nothing left behind
