@@ -54,6 +54,9 @@ extern "C" {
  * ("parity unpinned"): it is checked against the oracle's restatement of the same rule only. */
 #define LPX_PRICE_FIRST_NEGATIVE 0
 #define LPX_PRICE_DANTZIG 1
+/* ratio test of the tableau loop (lpx_tableau.ratio_rule) */
+#define LPX_RATIO_TEXTBOOK 0
+#define LPX_RATIO_HARRIS 1
 
 /* lpx_revised_iterate `kind` */
 #define LPX_KIND_PRIMAL 0  /* PrimalRevisedSimplexSolver.solve   primal_solvers.py:176-209 */
@@ -138,6 +141,13 @@ typedef struct lpx_tableau {
      * beside it.  The state is in T again whenever a call's work has drained; T_alt's contents are scratch between
      * calls.  Same arithmetic, same bits. */
     double *T_alt;
+    /* Ratio test of lpx_tableau_iterate: LPX_RATIO_TEXTBOOK (0, the reference's: primal_solvers.py:149-167, utils.py:5-10)
+     * or LPX_RATIO_HARRIS (opt-in, never the default; no counterpart in the reference): two passes with tolerance
+     * ratio_tol -- theta_max = min over d_i > 0 of (x_i + ratio_tol) / d_i, then among the rows with d_i > 0 and
+     * x_i / d_i <= theta_max the largest pivot d_i, first row on ties (oracle: lpo_ratio_harris).  Every other entry
+     * point takes LPX_RATIO_TEXTBOOK only. */
+    int64_t ratio_rule;
+    double ratio_tol;
 } lpx_tableau;
 
 /* ---------------------------------------------------------------------------------------------- misc */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblpx.so")
 RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
 VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
 PRICE_FIRST_NEGATIVE, PRICE_DANTZIG = 0, 1
+RATIO_TEXTBOOK, RATIO_HARRIS = 0, 1
 KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE = 0, 1, 2, 3, 4
 
 vp = C.c_void_p
@@ -54,6 +55,7 @@ class LpxTableau(C.Structure):
         ("log", vp), ("log_cap", i64),
         ("workspace", vp), ("workspace_bytes", i64),
         ("slot_var", vp), ("var_slot", vp), ("T_alt", vp),
+        ("ratio_rule", i64), ("ratio_tol", C.c_double),
     ]
 
 

@@ -37,6 +37,7 @@ struct TabWs {
     double *pend;    // partitioned dual loop with lookahead: {leaving row, optimal?, min x_B} decided one pivot ahead
     TbWs tb;         // deferred-update chain (lpx_tableau_blocked.hpp)
     TbWs tb2;        // pipelined chain: the pending pairs of every other block (E, Et, R, prow, pslot, rowflag, cnt of its own)
+    Partials ratio2; // Harris-style ratio test (opt-in): second-pass partials (largest pivot among the admissible rows)
     int64_t bytes;
 };
 static inline char *tcarve(char *&p, int64_t bytes)
@@ -96,6 +97,7 @@ static TabWs tab_ws(int64_t m, int64_t n, void *base)
     w.tb2.pslot = (int64_t *)tcarve(p, 8 * TB_KMAX);
     w.tb2.rowflag = (uint32_t *)tcarve(p, 4 * (m + 2));
     w.tb2.cnt = (int64_t *)tcarve(p, 8 * 2);
+    tcarve_partials(p, w.ratio2);
     w.bytes = (int64_t)(p - (char *)base);
     return w;
 }
@@ -120,6 +122,8 @@ static int check_tableau(const lpx_tableau *s)
     LPX_REQUIRE(s->slot_var != nullptr || (s->col0 >= 0 && s->n_global >= s->col0 + s->n), "bad column partition");
     LPX_REQUIRE(s->slot_var == nullptr || s->n_global >= s->n, "more slots than variables");
     LPX_REQUIRE(s->pricing == LPX_PRICE_FIRST_NEGATIVE || s->pricing == LPX_PRICE_DANTZIG, "bad pricing rule");
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK || (s->ratio_rule == LPX_RATIO_HARRIS && s->ratio_tol >= 0.0 && s->ratio_tol < 1.0),
+                "bad ratio rule / tolerance");
     return LPX_OK;
 }
 
@@ -213,6 +217,8 @@ __device__ __forceinline__ void t_ratio_partial(const lpx_tableau &s, int64_t i,
 {
     const bool in = i < s.m;
     VI t{in ? lpx_psd(s.T[i * s.ld + s.n], di, f32) : LPX_INF, in ? i : LPX_NOIDX};
+    // opt-in Harris-style test, pass 1: the largest step a tol-relaxed feasibility allows (float64 whatever the phase)
+    if (s.ratio_rule == LPX_RATIO_HARRIS) t.v = (in && di > 0.0) ? (s.T[i * s.ld + s.n] + s.ratio_tol) / di : LPX_INF;
     t = block_argmin(t, red);
     const double dmax = block_max(in ? di : -LPX_INF, red);
     if (threadIdx.x == 0) {
@@ -300,6 +306,26 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_t_select(lpx_tableau s, const dou
         d[i] = di;
     }
     t_ratio_partial(s, i, di, f32, R, red);
+}
+
+// Opt-in Harris-style ratio test, pass 2 (no counterpart in the reference, whose only test is primal_solvers.py:149-167;
+// oracle: lpo_ratio_harris): theta_max = min of the pass-1 partials; among the rows with d_i > 0 and x_i / d_i <= theta_max
+// the LARGEST pivot d_i wins, first row on ties.  Partials in k_t_prepare's format: (-d_i, row) for its argmin, max d.
+__global__ __launch_bounds__(LPX_BLOCK) void k_t_harris(lpx_tableau s, Partials R, int64_t nratio, const double *d, Partials R2)
+{
+    __shared__ BlockRed red;
+    if (s.ctrl->status != LPX_RUNNING) return;
+    const double tmax = combine_min(R.v0, nratio, red);
+    const int64_t i = (int64_t)blockIdx.x * LPX_BLOCK + threadIdx.x;
+    const bool in = i < s.m;
+    const double di = in ? d[i] : 0.0;
+    const bool ok = in && di > 0.0 && s.T[i * s.ld + s.n] / di <= tmax;
+    const VI t = block_argmin(VI{ok ? -di : LPX_INF, ok ? i : LPX_NOIDX}, red);
+    if (threadIdx.x == 0) {
+        R2.v0[blockIdx.x] = t.v;
+        R2.i0[blockIdx.x] = t.i;
+        R2.v1[blockIdx.x] = R.v1[blockIdx.x]; // max d of the same rows
+    }
 }
 
 // K1 prologue (tableau): leaving row, eta column (incl. the reduced-cost row's multiplier), old pivot row copy
@@ -1607,6 +1633,7 @@ extern "C" int lpx_tableau_block_begin(const lpx_tableau *s, void *stream)
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     tb_boot(s, tb_args(s, w), (hipStream_t)stream);
     LPX_LAUNCH_CHECK();
@@ -1616,6 +1643,7 @@ extern "C" int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, 
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
@@ -1629,6 +1657,7 @@ extern "C" int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, c
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
@@ -1647,6 +1676,7 @@ extern "C" int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(block == 8 || block == 16 || block == 32, "block size must be 8, 16 or 32");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     tb_flush(s, w, (int)block, (hipStream_t)stream);
@@ -1662,27 +1692,31 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
     if (iters <= 0) return LPX_OK;
-    if (const int kb = t_block_size(s)) {
+    // the opt-in Harris-style ratio test lives in the eager three-kernel chain only (one more small kernel per pivot)
+    const bool harris = s->ratio_rule == LPX_RATIO_HARRIS;
+    if (const int kb = harris ? 0 : t_block_size(s)) {
         // one block has nothing to overlap with: the in-place chain (shorter chains, no second buffer touched)
         if (t_use_pipeline(s) && iters > kb) return tableau_iterate_pipelined(s, w, iters, st, kb);
         return tableau_iterate_blocked(s, w, iters, st, kb);
     }
-    if (t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
+    if (!harris && t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");
     const int64_t nprice = plan.grid.x, nrow = lpx_cdiv(s->m + 1, LPX_BLOCK);
     // K1 refreshes the pricing partials of the NEXT iteration; the first iteration of a call scans the row itself
     t_launch_price(s, w, plan, st);
     const lpx_tableau sv = *s;
-    const bool small = t_is_small(s);
+    const bool small = t_is_small(s) && !harris;
     auto one = [&](hipStream_t q) {
         if (small) {
             hipLaunchKernelGGL((k_t_pre_small<false>), dim3(1), dim3(T_SMALL_THREADS), 0, q, sv, w.price, nprice,
                                (const double *)nullptr, (int64_t)0, (int64_t)0, w.d, w.e, w.rowr);
         } else {
             hipLaunchKernelGGL(k_t_column, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, q, sv, w.price, nprice, w.ratio, w.d);
+            if (harris)
+                hipLaunchKernelGGL(k_t_harris, dim3((unsigned)nrow), dim3(LPX_BLOCK), 0, q, sv, w.ratio, nrow, (const double *)w.d, w.ratio2);
             hipLaunchKernelGGL(k_t_prepare, dim3((unsigned)lpx_cdiv(t_prep_len(&sv), LPX_BLOCK)), dim3(LPX_BLOCK), 0, q, sv,
-                               w.ratio, nrow, (const double *)w.d, w.e, w.rowr);
+                               harris ? w.ratio2 : w.ratio, nrow, (const double *)w.d, w.e, w.rowr);
         }
         t_launch_update(&sv, w, plan, q);
     };
@@ -1697,6 +1731,7 @@ extern "C" int lpx_tableau_propose(const lpx_tableau *s, double *sendbuf, int re
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -1713,6 +1748,7 @@ extern "C" int lpx_tableau_commit(const lpx_tableau *s, const double *recvbuf, i
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -1807,6 +1843,7 @@ extern "C" int lpx_tableau_commit_begin(const lpx_tableau *s, const double *recv
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -1835,6 +1872,7 @@ extern "C" int lpx_tableau_commit_update(const lpx_tableau *s, void *stream)
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     // the pricing partials of the next pivot exist already (k_t_price_next) or are rescanned by lpx_tableau_propose
@@ -2193,6 +2231,7 @@ extern "C" int lpx_tableau_dual_block_begin(const lpx_tableau *s, void *stream)
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     const TbArgs a = tb_args(s, w);
     hipLaunchKernelGGL(k_tbd_boot, dim3((unsigned)lpx_cdiv(s->n > s->m + 1 ? s->n : s->m + 1, TB_THREADS)), dim3(TB_THREADS), 0,
@@ -2204,6 +2243,7 @@ extern "C" int lpx_tableau_dual_block_propose(const lpx_tableau *s, int64_t pend
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(sendbuf != nullptr && pending >= 0 && pending < TB_KMAX, "bad send buffer / pending count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     TbArgs a = tb_args(s, w);
@@ -2220,6 +2260,7 @@ extern "C" int lpx_tableau_dual_block_commit(const lpx_tableau *s, int64_t pendi
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     LPX_REQUIRE(pending >= 0 && pending < TB_KMAX, "bad pending count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
@@ -2238,6 +2279,7 @@ extern "C" int lpx_tableau_dual_iterate(const lpx_tableau *s, int64_t iters, voi
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n), "lpx_tableau_dual_iterate needs an unpartitioned tableau");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -2264,6 +2306,7 @@ extern "C" int lpx_tableau_dual_propose(const lpx_tableau *s, double *sendbuf, v
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(sendbuf != nullptr, "null send buffer");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -2280,6 +2323,7 @@ extern "C" int lpx_tableau_dual_commit(const lpx_tableau *s, const double *recvb
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -2300,6 +2344,7 @@ extern "C" int lpx_tableau_dual_commit_begin(const lpx_tableau *s, const double 
 {
     int rc = check_tableau(s);
     if (rc) return rc;
+    LPX_REQUIRE(s->ratio_rule == LPX_RATIO_TEXTBOOK, "the Harris-style ratio test is an option of lpx_tableau_iterate only");
     LPX_REQUIRE(recvbuf != nullptr && nranks >= 1 && nranks <= 64, "bad receive buffer / rank count");
     const TabWs w = tab_ws(s->m, s->n, s->workspace);
     hipStream_t st = (hipStream_t)stream;

@@ -111,7 +111,8 @@ class TableauEngine:
                           else int(os.environ.get("LPX_TABLEAU_PIPELINE_MIN_MB", "1024")) << 20)
 
     def __init__(self, T, m, n_local, basis, var_state, c_global, col0=0, n_global=None, log_cap=0, f32_phase=1,
-                 group=None, pricing="first_negative", dual=False, slot_var=None, var_slot=None):
+                 group=None, pricing="first_negative", dual=False, slot_var=None, var_slot=None, ratio="textbook",
+                 ratio_tol=1e-9):
         torch = torch_cuda()
         self.dual = bool(dual)
         self.slot_var, self.var_slot = slot_var, var_slot  # condensed form: nonbasic columns only (lpx.h)
@@ -138,6 +139,10 @@ class TableauEngine:
         s = self.s = _lib.LpxTableau()
         s.m, s.n, s.ld, s.col0, s.n_global = self.m, self.n, self.ld, self.col0, self.n_global
         s.pricing = {"first_negative": _lib.PRICE_FIRST_NEGATIVE, "dantzig": _lib.PRICE_DANTZIG}[pricing]
+        s.ratio_rule = {"textbook": _lib.RATIO_TEXTBOOK, "harris": _lib.RATIO_HARRIS}[ratio]
+        s.ratio_tol = float(ratio_tol)
+        if s.ratio_rule != _lib.RATIO_TEXTBOOK and (group is not None or dual):
+            raise ValueError("ratio='harris' is an option of the unpartitioned primal tableau loop only")
         s.T, s.basis, s.var_state, s.ctrl = T.data_ptr(), basis.data_ptr(), var_state.data_ptr(), self.ctrl.data_ptr()
         s.log = self.log.data_ptr() if self.log_cap > 0 else None
         s.log_cap = self.log_cap
@@ -373,9 +378,13 @@ class PrimalTableauSimplexSolver:
     #: carry only the nonbasic columns (same numbers, half the memory and HBM traffic at n = 2m); False = every column
     CONDENSED = os.environ.get("LPX_TABLEAU_CONDENSED", "1") != "0"
 
-    def __init__(self, c, A, b, basis, group=None, columns=None, n_global=None, pricing="first_negative", condensed=None):
+    def __init__(self, c, A, b, basis, group=None, columns=None, n_global=None, pricing="first_negative", condensed=None,
+                 ratio="textbook", ratio_tol=1e-9):
         """``pricing="dantzig"`` (most negative reduced cost) is an opt-in extension: the reference's standard-form
-        solvers only have the first-negative-index rule, which stays the default."""
+        solvers only have the first-negative-index rule, which stays the default.  ``ratio="harris"``: a Harris-style
+        two-pass ratio test with tolerance ``ratio_tol`` (lpx.h, lpx_tableau.ratio_rule) instead of the reference's
+        textbook test (primal_solvers.py:149-167) -- opt-in as well, parity unpinned against the reference (it has no
+        such rule), bit-exact against the oracle's restatement of the same rule."""
         condensed = self.CONDENSED if condensed is None else bool(condensed)
         var_ids = None
         if columns is None:
@@ -423,7 +432,8 @@ class PrimalTableauSimplexSolver:
         self.optimum = None
         self._engine = TableauEngine.from_columns(A_cols, self.b, self.c, self.basis, j0, self.n, inv32=inv32,
                                                   bfs32=bfs32, log_cap=self._LOG_CAP, group=group, pricing=pricing,
-                                                  var_ids=var_ids, condensed=condensed, start32=start32)
+                                                  var_ids=var_ids, condensed=condensed, start32=start32, ratio=ratio,
+                                                  ratio_tol=ratio_tol)
 
     @staticmethod
     def _slack_block_is_identity(A_cols, j0, j1, k):

@@ -134,6 +134,31 @@ void lpo_ratio_primal(const double *x, const double *d, int64_t m, int f32, int6
     *dmax_out = dmax;
 }
 
+/* Harris-style two-pass ratio test (the build's opt-in extension; the reference has only the textbook test above, so
+ * this restates the BUILD's stated rule, parity unpinned against the reference):
+ *   pass 1: theta_max = min over d_i > 0 of (x_i + tol) / d_i          (the step a tol-relaxed feasibility allows)
+ *   pass 2: among rows with d_i > 0 and x_i / d_i <= theta_max, the one with the LARGEST pivot d_i, first on ties.
+ * Quotients in float64 whatever the float32 phase.  theta_out = x_r / d_r. */
+void lpo_ratio_harris(const double *x, const double *d, int64_t m, double tol, int64_t *r_out, double *theta_out,
+                      double *dmax_out)
+{
+    double tmax = INFINITY, dmax = -INFINITY;
+    for (int64_t i = 0; i < m; ++i) {
+        if (d[i] > 0) {
+            const double t = (x[i] + tol) / d[i];
+            if (t < tmax) tmax = t;
+        }
+        if (d[i] > dmax) dmax = d[i];
+    }
+    int64_t r = 0;
+    double best = -INFINITY;
+    for (int64_t i = 0; i < m; ++i)
+        if (d[i] > 0 && x[i] / d[i] <= tmax && d[i] > best) { best = d[i]; r = i; }
+    *r_out = r;
+    *theta_out = (dmax > 0) ? x[r] / d[r] : INFINITY;
+    *dmax_out = dmax;
+}
+
 /* dual_solvers.py:61-80 + utils.py:12-17: theta_j = (-rc_j)/row_j if row_j<0 else inf; FIRST argmin.
  * Also returns min(row) for dual_solvers.py:56-59. */
 void lpo_ratio_dual(const double *rc, const double *row, const int32_t *var_state, int64_t n, int f32,
@@ -572,6 +597,10 @@ typedef struct lpo_tableau {
     int32_t threads; /* >1: OpenMP update */
     int32_t pricing; /* 0: first negative reduced cost (the reference's rule); 1: Dantzig, most negative, first index
                         on ties -- the build's opt-in extension, no counterpart in the reference */
+    int32_t ratio_rule; /* 0: the reference's textbook ratio test (primal_solvers.py:149-167); 1: Harris-style two-pass
+                           test with tolerance ratio_tol -- opt-in extension, no counterpart in the reference */
+    int32_t pad_;
+    double ratio_tol;
 } lpo_tableau;
 
 int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
@@ -599,7 +628,8 @@ int lpo_tableau_solve(lpo_tableau *s, int64_t maxiters)
         for (int64_t i = 0; i < m; ++i) xcol[i] = s->T[i * ld + n];
         int64_t r;
         double theta, dmax;
-        lpo_ratio_primal(xcol, s->d, m, s->f32_phase, &r, &theta, &dmax); /* :149-167 */
+        if (s->ratio_rule == 1) lpo_ratio_harris(xcol, s->d, m, s->ratio_tol, &r, &theta, &dmax);
+        else lpo_ratio_primal(xcol, s->d, m, s->f32_phase, &r, &theta, &dmax); /* :149-167 */
         if (dmax <= 0) { s->status = LPO_PRIMAL_UNBOUNDED; break; }
         const double dr = s->d[r];
         for (int64_t i = 0; i <= m; ++i) s->e[i] = (-s->d[i]) / dr; /* :236-244 */
@@ -658,7 +688,8 @@ int lpo_tableau_solve_condensed(lpo_tableau *s, int64_t *slot_var, int64_t maxit
         for (int64_t i = 0; i < m; ++i) xcol[i] = s->T[i * ld + n];
         int64_t r;
         double theta, dmax;
-        lpo_ratio_primal(xcol, s->d, m, s->f32_phase, &r, &theta, &dmax); /* :149-167 */
+        if (s->ratio_rule == 1) lpo_ratio_harris(xcol, s->d, m, s->ratio_tol, &r, &theta, &dmax);
+        else lpo_ratio_primal(xcol, s->d, m, s->f32_phase, &r, &theta, &dmax); /* :149-167 */
         if (dmax <= 0) { s->status = LPO_PRIMAL_UNBOUNDED; break; }
         const double dr = s->d[r];
         for (int64_t i = 0; i <= m; ++i) s->e[i] = (-s->d[i]) / dr; /* :236-244 */

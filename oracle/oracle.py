@@ -55,6 +55,7 @@ class _Tableau(C.Structure):
         ("counter", C.c_int64), ("pivots", C.c_int64),
         ("log", _ip), ("log_cap", C.c_int64),
         ("d", _dp), ("e", _dp), ("rowr", _dp), ("threads", C.c_int32), ("pricing", C.c_int32),
+        ("ratio_rule", C.c_int32), ("pad_", C.c_int32), ("ratio_tol", C.c_double),
     ]
 
 
@@ -423,13 +424,15 @@ class OracleTableau:
     """Tableau-form restatement (lpo_tableau_solve): carries T = B^-1 A, x_B and the reduced-cost row."""
 
     def __init__(self, c, A, b, basis, log_cap=1 << 16, ld=None, threads=1, check=True, pricing=0, kind="primal",
-                 condensed=False):
+                 condensed=False, ratio="textbook", ratio_tol=1e-9):
         """kind = "dual": the dual simplex rules on the same tableau (lpo_tableau_dual_solve); the constructor then
         checks dual instead of primal feasibility of the starting basis (dual_solvers.py:14-16).
         condensed (primal only): carry the nonbasic columns only (lpo_tableau_solve_condensed), the layout the GPU
         tableau solver uses by default; ``slot_var[k]`` is the variable in column slot k, column ``nslots`` is x_B."""
         self.kind = kind
         self.condensed = bool(condensed)
+        self.ratio, self.ratio_tol = ratio, float(ratio_tol)  # "harris": lpo_ratio_harris (opt-in, primal loops only)
+        assert ratio in ("textbook", "harris") and not (ratio == "harris" and kind != "primal")
         assert not (condensed and kind != "primal")
         self.c, A32, self.b = preprocess(c, A, b)
         self.m, self.n = A32.shape
@@ -497,6 +500,7 @@ class OracleTableau:
         s.log, s.log_cap = _p(self.log, _ip), log_cap
         s.d, s.e, s.rowr, s.threads = _p(self._d, _dp), _p(self._e, _dp), _p(self._rowr, _dp), threads
         s.pricing = int(pricing)
+        s.ratio_rule, s.ratio_tol = (1 if self.ratio == "harris" else 0), self.ratio_tol
 
     def solve(self, maxiters=100):
         if self.condensed:

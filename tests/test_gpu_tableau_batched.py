@@ -728,3 +728,49 @@ def test_batched_bounded_reentrant_and_upper_bound_start():
             w = o.solve(k)
             assert res[i].iters == w.iters and res[i].basis.tolist() == w.basis.tolist() and np.array_equal(res[i].x, w.x)
             assert bool(res[i].optimum) == (w.status == O.OPTIMAL)
+
+
+@pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
+@pytest.mark.parametrize("gen_name,m,n,seed", [("gen_primal", 64, 128, 1), ("gen_primal", 300, 700, 2), ("gen_primal", 530, 1061, 3),
+                                                ("gen_primal_degenerate", 32, 64, 0), ("gen_primal_degenerate", 32, 64, 1),
+                                                ("gen_primal_degenerate", 64, 128, 2)])
+def test_harris_ratio_test_opt_in(gen_name, m, n, seed, condensed):
+    """ratio="harris" (north_star's "Harris-style ratio test"; the reference has only the textbook test,
+    primal_solvers.py:149-167, so this is PARITY UNPINNED against it and never the default): two passes with a 1e-9
+    tolerance, largest pivot among the admissible rows.  Bit-exact against the oracle's restatement of the same rule
+    (lpo_ratio_harris: pivot log, whole tableau), x_B >= -tol-scale, and the optimum is the LP's (scipy HiGHS)."""
+    from scipy.optimize import linprog
+
+    from linprog_amd.tableau import PrimalTableauSimplexSolver
+    from oracle import oracle as O
+
+    c, A, b, basis = getattr(gen, gen_name)(m, n, seed)
+    cls = type("L", (PrimalTableauSimplexSolver,), {"_LOG_CAP": 8192})
+    s = cls(c, A, b, basis, condensed=condensed, ratio="harris")
+    o = O.OracleTableau(c, A, b, basis, condensed=condensed, log_cap=8192, ratio="harris")
+    for k in (7, 100000):
+        res, want = s.solve(k), o.solve(k)
+        assert s.pivot_log().tolist() == o.log[:len(s.pivot_log())].tolist() and res.iters == want.iters
+        w = o.nslots + 1
+        assert np.array_equal(s._engine.T.cpu().numpy()[:, :w], o.T[:, :w])
+    assert res.optimum and np.array_equal(res.x, want.x) and res.x.min() >= -1e-7
+    A32, b32, c32 = (np.asarray(v, dtype=np.float32).astype(float) for v in (A, b, c))
+    hs = linprog(c32, A_eq=A32, b_eq=b32, method="highs")
+    assert hs.status == 0 and abs(res.cost - hs.fun) <= 1e-7 * max(1.0, abs(hs.fun))
+    # the default rule on the same LP ends on the same optimum (by another path on the degenerate inputs)
+    t = PrimalTableauSimplexSolver(c, A, b, basis, condensed=condensed).solve(100000)
+    assert t.optimum and abs(t.cost - res.cost) <= 1e-7 * max(1.0, abs(t.cost))
+
+
+def test_harris_is_refused_outside_the_unpartitioned_primal_loop():
+    import ctypes as C
+
+    from linprog_amd import _lib
+    from linprog_amd.tableau import DualTableauSimplexSolver, PrimalTableauSimplexSolver
+
+    c, A, b, basis = gen.gen_primal(40, 90, 1)
+    eng = PrimalTableauSimplexSolver(c, A, b, basis, ratio="harris")._engine
+    lib = _lib.load()
+    assert lib.lpx_tableau_dual_iterate(C.byref(eng.s), 4, None) == -1 and b"Harris" in lib.lpx_last_error()
+    eng.s.ratio_tol = -1.0
+    assert lib.lpx_tableau_iterate(C.byref(eng.s), 4, None) == -1
