@@ -64,6 +64,15 @@ extern "C" {
 #define LPX_KIND_BOUNDED 2 /* BoundedVariablePrimalSimplexSolver.solve  special_solvers.py:221-343 */
 #define LPX_KIND_PRIMAL_NAIVE 3 /* PrimalNaiveSimplexSolver.solve: float32 re-inversion per pivot, :92-94, :169-174 */
 #define LPX_KIND_DUAL_NAIVE 4   /* DualNaiveSimplexSolver.solve */
+/* Opt-in extension, lpx_revised_solve_small / _batch only: the DUAL simplex for lb <= x <= ub (BASELINE config 5's "dual
+ * simplex with bounded variables").  No counterpart in the reference -- its bounded solver is the primal one
+ * (special_solvers.py:94-343), its dual solver knows x >= 0 only (dual_solvers.py:47-108) -- so parity is unpinned against
+ * it; the rules are the reference's dual rules generalised: leaving row = first basic variable outside its bounds
+ * (optimal when the worst violation is <= 1e-8), ratio test theta_j = (-rc_j) / alpha_j over the nonbasic columns that
+ * can repair it (at lower with alpha_j < 0, at upper with alpha_j > 0; alpha = the dual row, negated when x_r is above
+ * its bound), first argmin; the leaving variable goes to the bound it violated; x_B recomputed as :169-175.  float64
+ * throughout.  Oracle: lpo_dual_bounded_solve. */
+#define LPX_KIND_DUAL_BOUNDED 5
 
 /* Device-resident control block (128 bytes).  Written only by kernels (and by lpx_ctrl_reset); the host
  * reads it with lpx_read_ctrl.  `counter` is the reference's self.counter. */
@@ -182,7 +191,8 @@ int64_t lpx_revised_workspace_bytes(int64_t m, int64_t n);
  *   BoundedVariablePrimalSimplexSolver.solve    special_solvers.py:225-341. */
 int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *stream);
 
-/* The same loops as ONE launch for a small LP (kind = LPX_KIND_PRIMAL, LPX_KIND_DUAL or LPX_KIND_BOUNDED): a whole solve()
+/* The same loops as ONE launch for a small LP (kind = LPX_KIND_PRIMAL, LPX_KIND_DUAL, LPX_KIND_BOUNDED or the opt-in
+ * LPX_KIND_DUAL_BOUNDED): a whole solve()
  * call -- up to `maxiters` iterations of primal_solvers.py:191-207 / dual_solvers.py:96-106 / special_solvers.py:225-341 --
  * by one workgroup with B^-1 in LDS, state read from and written back to *s (control block included; call
  * lpx_ctrl_begin_solve first, as for lpx_revised_iterate).  A single LP of a few hundred rows is launch-bound on the

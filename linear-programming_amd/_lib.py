@@ -17,7 +17,7 @@ RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
 VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
 PRICE_FIRST_NEGATIVE, PRICE_DANTZIG = 0, 1
 RATIO_TEXTBOOK, RATIO_HARRIS = 0, 1
-KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE = 0, 1, 2, 3, 4
+KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE, KIND_DUAL_BOUNDED = 0, 1, 2, 3, 4, 5
 
 vp = C.c_void_p
 i64 = C.c_int64

@@ -967,12 +967,13 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
     L.d = (double *)take(8 * m);
     L.e = (double *)take(8 * m);
     L.rowr = (double *)take(8 * m);
-    L.w = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * m : 0);
+    const bool bnd = kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED;
+    L.w = (double *)take(bnd ? 8 * m : 0);
     L.rc = (double *)take(8 * n);
     L.row = (double *)take(kind == LPX_KIND_DUAL ? 8 * n : 0);
-    L.lb = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
-    L.ub = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
-    L.bu = (double *)take(kind == LPX_KIND_BOUNDED ? 8 * n : 0);
+    L.lb = (double *)take(bnd ? 8 * n : 0);
+    L.ub = (double *)take(bnd ? 8 * n : 0);
+    L.bu = (double *)take(bnd ? 8 * n : 0);
     L.yd = (double *)take(kind == LPX_KIND_PD ? 8 * m : 0);
     L.v = (double *)take(kind == LPX_KIND_PD ? 8 * n : 0);
     L.c = (float *)take(4 * n);
@@ -1034,6 +1035,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         ldA = ldl;
         At = nullptr; // a row of the LDS copy is read as it lies
     }
+    // both bounded-variable loops: the primal one (special_solvers.py:94-343) and the opt-in dual one (lpx.h, LPX_KIND_DUAL_BOUNDED)
+    constexpr bool BND = KIND == LPX_KIND_BOUNDED || KIND == LPX_KIND_DUAL_BOUNDED;
     const int n_orig = PD ? (int)a.pd_n_orig : 0;
     int64_t outer = 0;
     int pd_status = LPX_RUNNING;
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     for (int j = t; j < n; j += LPX_BLOCK) {
         L.c[j] = s.c[j];
         L.vstate[j] = s.var_state[j];
-        if (KIND == LPX_KIND_BOUNDED) {
+        if (BND) {
             L.lb[j] = s.lb[j];
             L.ub[j] = s.ub[j];
         }
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     __syncthreads();
     if (t < m) L.cb[t] = L.c[L.basis[t]];
     if (PD && t < m) L.yd[t] = a.pd_y[t];
-    bool f32 = ctrl->f32_phase != 0;
+    bool f32 = ctrl->f32_phase != 0 && KIND != LPX_KIND_DUAL_BOUNDED; // the opt-in bounded dual loop is float64 throughout
     int status = LPX_RUNNING;
     int64_t counter = ctrl->counter, pivots = ctrl->pivots;
     int last_j = -1, last_r = -1, last_leaving = -1, last_flip = 0, last_lstate = 0;
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         if (t < m) L.xB[t] = batch_dot<double>(L.Binv + t * ldb, 1, L.w, 1, m);
         __syncthreads();
     };
-    if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs();
+    if (BND) bounded_update_bfs();
 
     BS_DECL
     do { // one pass, or the outer loop of the primal-dual algorithm
@@ -1132,6 +1135,28 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                 break;
             }
             r = first;
+        }
+        bool below = false;
+        if (KIND == LPX_KIND_DUAL_BOUNDED) {
+            // leaving row: the FIRST basic variable outside its bounds; optimal when the worst violation is <= 1e-8
+            // (dual_solvers.py:47-54 with "x_i < 0" read as "outside [lb, ub]"; oracle: lpo_dual_bounded_solve)
+            double neg = LPX_INF; // -(violation): min over the rows = -(worst violation)
+            int first = 0x7FFFFFFF;
+            if (t < m) {
+                const int bv = L.basis[t];
+                const double x = L.xB[t], lo = L.lb[bv] - x, hi = x - L.ub[bv];
+                const double inf = lo > hi ? lo : hi;
+                neg = -inf;
+                if (inf > 0.0) first = t;
+            }
+            batch_min_imin(neg, first, red);
+            last_price = neg;
+            if (lpx_is_optimal_min(neg)) {
+                status = LPX_OPTIMAL;
+                break;
+            }
+            r = first;
+            below = L.xB[r] < L.lb[L.basis[r]];
         }
         // ---- y = c_B @ B^-1 (primal_solvers.py:64, first product): one lane per column, i ascending
         if (t < m)
@@ -1180,6 +1205,29 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             double negmin = -rowmin;
             batch_argmin_max(th, jn, negmin, red); // first argmin of theta; max(-row) = -min(row)
             if (-negmin >= 0.0) { // dual_solvers.py:41-44
+                status = LPX_DUAL_UNBOUNDED;
+                break;
+            }
+            j = jn;
+        } else if (KIND == LPX_KIND_DUAL_BOUNDED) {
+            // ratio test over the nonbasic columns: alpha = row when x_r sits below its bound, -row above; candidates are
+            // "at lower with alpha < 0" and "at upper with alpha > 0"; theta = (-rc) / alpha, first argmin (utils.py:12-17)
+            double th = LPX_INF, dummy = 0.0;
+            int jn = 0x7FFFFFFF;
+            for (int col = t; col < n; col += LPX_BLOCK) {
+                const int vs = L.vstate[col];
+                if (vs != LPX_VS_LOWER && vs != LPX_VS_UPPER) continue;
+                const double rc = (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+                const double row = block_dot_g<double, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                const double alpha = below ? row : -row;
+                if ((vs == LPX_VS_LOWER && alpha < 0.0) || (vs == LPX_VS_UPPER && alpha > 0.0)) {
+                    const double tj = (-rc) / alpha;
+                    if (jn == 0x7FFFFFFF || tj < th) { th = tj; jn = col; } // columns ascend per lane: first minimum
+                }
+            }
+            if (jn == 0x7FFFFFFF) th = LPX_INF;
+            batch_argmin_max(th, jn, dummy, red);
+            if (jn == 0x7FFFFFFF) { // no column can repair row r: the primal is infeasible (dual_solvers.py:41-44)
                 status = LPX_DUAL_UNBOUNDED;
                 break;
             }
@@ -1260,6 +1308,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             else if (g1 < g2) { r = r1; lstate = LPX_VS_LOWER; } // :271-277
             else { r = r2; lstate = LPX_VS_UPPER; }              // :278-284
         } else {
+            if (KIND == LPX_KIND_DUAL_BOUNDED) lstate = below ? LPX_VS_LOWER : LPX_VS_UPPER; // the bound it violated
             __syncthreads(); // L.d complete
         }
         BS(3)
@@ -1298,7 +1347,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                         if (row[u] >= 0) L.Binv[off[u]] = (row[u] == r) ? ei[u] * rk[u] : fma(ei[u], rk[u], bv[u]);
                 }
             }
-            if (KIND != LPX_KIND_BOUNDED && t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]); // :251-253
+            if (!BND && t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]); // :251-253
         }
         BS(4)
         if (t == 0) {
@@ -1319,7 +1368,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         last_j = j; last_r = flip ? -1 : r; last_leaving = leaving; last_flip = flip ? 1 : 0; last_lstate = lstate;
         if (!flip) f32 = false;
         __syncthreads();
-        if (KIND == LPX_KIND_BOUNDED) bounded_update_bfs(); // special_solvers.py:341
+        if (BND) bounded_update_bfs(); // special_solvers.py:341
     }
     if (PD) {
         __syncthreads();
@@ -1383,8 +1432,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     if (a.x != nullptr) { // result assembly, primal_solvers.py:72-79 / special_solvers.py:201-206; cost in index order
         for (int col = t; col < n; col += LPX_BLOCK) {
             const int vs = L.vstate[col];
-            L.rc[col] = (KIND == LPX_KIND_BOUNDED && vs == LPX_VS_LOWER) ? L.lb[col]
-                        : (KIND == LPX_KIND_BOUNDED && vs == LPX_VS_UPPER) ? L.ub[col] : 0.0;
+            L.rc[col] = (BND && vs == LPX_VS_LOWER) ? L.lb[col] : (BND && vs == LPX_VS_UPPER) ? L.ub[col] : 0.0;
         }
         __syncthreads();
         if (t < m) L.rc[L.basis[t]] = L.xB[t];
@@ -1418,7 +1466,8 @@ extern "C" int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind)
 
 static int block_launch(const BlockArgs &a0, int64_t batch, int64_t m, int64_t n, int kind, hipStream_t st)
 {
-    LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED, "kind must be primal, dual or bounded");
+    LPX_REQUIRE(kind == LPX_KIND_PRIMAL || kind == LPX_KIND_DUAL || kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED,
+                "kind must be primal, dual, bounded or dual-bounded");
     int64_t bytes = block_lds(m, n, kind, nullptr).bytes;
     if (bytes > LPX_BLOCK_LDS_MAX || m > 4096 || n > 65536) {
         lpx_set_error("lpx_revised_solve_small: the state of a %lld x %lld LP needs %lld B of LDS, one CU has %d", (long long)m,
@@ -1435,6 +1484,7 @@ static int block_launch(const BlockArgs &a0, int64_t batch, int64_t m, int64_t n
     }
     if (kind == LPX_KIND_PRIMAL) LPX_BLOCK_GO(LPX_KIND_PRIMAL)
     else if (kind == LPX_KIND_DUAL) LPX_BLOCK_GO(LPX_KIND_DUAL)
+    else if (kind == LPX_KIND_DUAL_BOUNDED) LPX_BLOCK_GO(LPX_KIND_DUAL_BOUNDED)
     else LPX_BLOCK_GO(LPX_KIND_BOUNDED)
 #undef LPX_BLOCK_GO
     LPX_LAUNCH_CHECK();
@@ -1446,7 +1496,7 @@ extern "C" int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t m
     LPX_REQUIRE(s != nullptr && s->m > 0 && s->n > 0 && maxiters >= 0, "bad state / sizes");
     LPX_REQUIRE(s->A && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
     LPX_REQUIRE(s->ldA >= s->n && s->ldB >= s->m, "leading dimensions too small");
-    LPX_REQUIRE(kind != LPX_KIND_BOUNDED || (s->lb && s->ub), "the bounded solver needs lb and ub");
+    LPX_REQUIRE((kind != LPX_KIND_BOUNDED && kind != LPX_KIND_DUAL_BOUNDED) || (s->lb && s->ub), "the bounded solvers need lb and ub");
     BlockArgs a{};
     a.single = *s;
     a.states = nullptr;

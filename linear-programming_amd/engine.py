@@ -97,7 +97,8 @@ class RevisedEngine:
     #: rows up to which the one-launch kernel beats the chain (tools/small_solve_bench.py on MI355X: per iteration at
     #: m = 64 / 128 -- dual 10 / 21 us against the chain's 28 / 28; bounded, whose x_B is recomputed from scratch through
     #: an n-long chain every iteration, 30 / 55 us against 42 / 41)
-    SMALL_MAX_ROWS = {_lib.KIND_PRIMAL: 128, _lib.KIND_DUAL: 128, _lib.KIND_BOUNDED: 96}
+    SMALL_MAX_ROWS = {_lib.KIND_PRIMAL: 128, _lib.KIND_DUAL: 128, _lib.KIND_BOUNDED: 96,
+                      _lib.KIND_DUAL_BOUNDED: 4096}  # the opt-in bounded dual loop exists as the one-launch kernel only
 
     def fits_small(self, kind):
         return (self.SMALL_SOLVE and not self.naive and not self.refine_every and not self.reinvert_every

@@ -69,6 +69,26 @@ def gen_primal_degenerate(m, n, seed):
     return c, A, b, np.arange(k, n)
 
 
+def gen_box_dual(m, n, seed):
+    """Box-bounded LP with a DUAL feasible, primal infeasible start for the bounded-variable dual simplex (BASELINE
+    config 5's wording; the build's opt-in solver -- the reference has none): costs of both signs, every structural
+    variable nonbasic at the bound its cost prefers (upper when c_j < 0, else lower), slack basis.  Feasible by
+    construction (x = ub / 2 leaves positive slacks); the slacks are free above (+inf)."""
+    rng = np.random.default_rng(seed)
+    k = n - m
+    G = rng.uniform(0, 1, (m, k))
+    A = np.hstack([G, np.eye(m)])
+    ubx = rng.uniform(0.5, 1.5, k)
+    b = G @ (0.5 * ubx) + rng.uniform(0.1, 1, m)
+    c = np.concatenate([rng.uniform(-1, 1, k), np.zeros(m)])
+    lb = np.zeros(n)
+    ub = np.concatenate([ubx, np.inf * np.ones(m)])
+    basis = np.arange(k, n)
+    at_upper = np.flatnonzero(c[:k].astype(np.float32) < 0)
+    at_lower = np.flatnonzero(c[:k].astype(np.float32) >= 0)
+    return c, A, b, lb, ub, basis, at_lower, at_upper
+
+
 def gen_box(m, n, seed):
     """Box-bounded LP for BoundedVariablePrimalSimplexSolver (reference limit: m <= 170)."""
     rng = np.random.default_rng(seed)

@@ -13,7 +13,7 @@ from . import _lib
 from .data_classes import LinProgResult
 from .device import stream_ptr, to_device, torch_cuda
 from .engine import RevisedEngine
-from .exceptions import DualIsUnboundedError, PrimalIsInfeasibleError, PrimalIsUnboundedError
+from .exceptions import BasisIsDualInfeasibleError, DualIsUnboundedError, PrimalIsInfeasibleError, PrimalIsUnboundedError
 from .preprocessing import DeviceProblem, ProblemPreprocessingUtils
 from .dual_solvers import DualRevisedSimplexSolver
 from .primal_solvers import PrimalRevisedSimplexSolver, _initial_inverse
@@ -139,6 +139,64 @@ class BoundedVariablePrimalSimplexSolver(PrimalRevisedSimplexSolver):
             raise PrimalIsUnboundedError  # special_solvers.py:256-257 / :302-303
         if status == _lib.NOT_NONBASIC:
             raise ValueError("Column to enter basis is not nonbasic.")  # :331
+
+
+class BoundedVariableDualSimplexSolver(BoundedVariablePrimalSimplexSolver):
+    """OPT-IN EXTENSION, no counterpart in the reference: the DUAL simplex for ``lb <= x <= ub`` without bound rows
+    (BASELINE.json config 5: "box-bounded random LP via dual simplex with bounded variables").  The reference has the
+    bounded PRIMAL solver (special_solvers.py:94-343) and a dual solver for ``x >= 0`` (dual_solvers.py:47-108) only, so
+    parity is unpinned against it; the rules are the reference's dual rules generalised (include/lpx.h,
+    LPX_KIND_DUAL_BOUNDED), the arithmetic is checked bit for bit against the oracle's restatement
+    (lpo_dual_bounded_solve) and the answers against HiGHS.
+
+    Same constructor as the bounded primal solver.  The start must be DUAL feasible -- reduced cost >= 0 for the
+    nonbasic variables at their lower bound, <= 0 for those at their upper bound, else ``BasisIsDualInfeasibleError``
+    (dual_solvers.py:14-16 read for two bounds; float32 like the reference's check) -- and may be primal infeasible.
+    Infinite bounds stay infinite.  ``solve`` raises ``DualIsUnboundedError`` when the primal is infeasible (:41-44).
+    One launch per ``solve()`` call (lpx_revised_solve_small): the state must fit one CU's LDS (m <= 128 at n = 2m)."""
+
+    _KIND = _lib.KIND_DUAL_BOUNDED
+
+    def __init__(self, c, A, b, lb, ub, basis, lb_nonbasic_vars, ub_nonbasic_vars):
+        self.c, self.A, self.b = self._preprocess_problem(c, A, b)
+        self.lb = np.array(lb, dtype=np.float64)
+        self.ub = np.array(ub, dtype=np.float64)
+        self.m, self.n = self.A.shape
+        self.row_offset = 1
+        self.col_offset = 1
+        self.basis = np.array(basis).astype(int)
+        lbn = np.array(lb_nonbasic_vars).astype(int)
+        ubn = np.array(ub_nonbasic_vars).astype(int)
+        if np.any(np.isinf(self.lb[lbn])) or np.any(np.isinf(self.ub[ubn])):
+            raise ValueError("a nonbasic variable cannot sit at an infinite bound")
+        inv32, _ = _initial_inverse(self.A, self.basis, self.b)
+        rc32 = self.c - self.c[self.basis] @ inv32 @ self.A  # dual_solvers.py:14-16, float32
+        if np.any(rc32[lbn] < 0) or np.any(rc32[ubn] > 0):
+            raise BasisIsDualInfeasibleError
+        var_state = np.full(self.n, _lib.VS_EXCLUDED, dtype=np.int32)
+        var_state[lbn] = _lib.VS_LOWER
+        var_state[ubn] = _lib.VS_UPPER
+        var_state[self.basis] = _lib.VS_BASIC
+        self._engine = RevisedEngine(self.c, self.A, self.b, self.basis, inv32, np.zeros(self.m), var_state=var_state,
+                                     lb=self.lb, ub=self.ub, log_cap=self._LOG_CAP)
+        if not self._engine.fits_small(self._KIND):
+            raise ValueError(f"the bounded-variable dual simplex is a one-launch kernel: the state of a {self.m} x {self.n} LP "
+                             "does not fit one CU's LDS (m <= 128 at n = 2m)")
+        self._engine.bounded_update_bfs()
+        self.counter = None
+        self.optimum = None
+
+    def solve(self, maxiters: int = 100):
+        """``optimum`` stays ``None`` until optimality is reached, as for the reference's dual solvers (dual_solvers.py:95-102)."""
+        self.counter = 0
+        ctrl = self._engine.run(self._KIND, maxiters)
+        self.counter = int(ctrl.counter)
+        if ctrl.status == _lib.DUAL_UNBOUNDED:
+            self._sync_basis()
+            raise DualIsUnboundedError
+        if ctrl.status == _lib.OPTIMAL:
+            self.optimum = True
+        return self._get_solver_return_object()
 
 
 class PrimalDualAlgorithm(DualRevisedSimplexSolver):

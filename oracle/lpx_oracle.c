@@ -533,6 +533,72 @@ int lpo_bounded_solve(lpo_revised *s, int64_t maxiters)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Bounded-variable DUAL simplex -- the build's opt-in extension for BASELINE config 5's wording ("dual simplex with
+ * bounded variables").  The reference has no such solver (its bounded solver is the primal one above, its dual solver
+ * knows x >= 0 only: special_solvers.py:94-343, dual_solvers.py:47-108), so this restates the BUILD's stated rules and is
+ * parity unpinned against the reference.  Rules, the reference's dual rules generalised to lb <= x <= ub, all float64:
+ *   leaving row   = FIRST row whose basic variable violates a bound (x_i < lb or x_i > ub); optimal when the worst
+ *                   violation is <= 1e-8 (dual_solvers.py:47-54 with "x_i < 0" read as "outside its bounds")
+ *   dual row      = B^-1[r, :] @ A, reduced costs c - c_B B^-1 A (dual_solvers.py:37-40, :77), basic columns 0
+ *   ratio test    = alpha_j = row_j when x_r is BELOW its bound, -row_j when above; candidates: nonbasic at lower with
+ *                   alpha_j < 0, nonbasic at upper with alpha_j > 0; theta_j = (-rc_j) / alpha_j; FIRST argmin
+ *                   (dual_solvers.py:61-80, utils.py:12-17); no candidate = the primal is infeasible (:41-44)
+ *   pivot         = eta column from d = B^-1 A_j (primal_solvers.py:217-249); the leaving variable goes to the bound it
+ *                   violated; x_B = B^-1 (b - A_lb lb - A_ub ub) from scratch as the bounded primal does (:169-175)
+ * ---------------------------------------------------------------------------------------------- */
+int lpo_dual_bounded_solve(lpo_revised *s, int64_t maxiters)
+{
+    const int64_t m = s->m, n = s->n;
+    s->counter = 0;
+    s->status = LPO_RUNNING;
+    s->f32_phase = 0;
+    lpo_bounded_update_bfs(s);
+    while (s->counter < maxiters) {
+        s->counter += 1;
+        double worst = -INFINITY;
+        int64_t r = -1;
+        int below = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            const double lo = s->lb[s->basis[i]], hi = s->ub[s->basis[i]], x = s->xB[i];
+            const double inf = (lo - x > x - hi) ? lo - x : x - hi;
+            if (inf > worst) worst = inf;
+            if (r < 0 && inf > 0) { r = i; below = x < lo; }
+        }
+        if (worst <= ISCLOSE_ATOL) {
+            s->status = LPO_OPTIMAL;
+            break;
+        }
+        lpo_dual_row(s, r);
+        lpo_price(s);
+        double best = INFINITY;
+        int64_t j = -1;
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t vs = s->var_state[k];
+            if (vs != VS_LOWER && vs != VS_UPPER) continue;
+            const double alpha = below ? s->row[k] : -s->row[k];
+            if ((vs == VS_LOWER && alpha < 0) || (vs == VS_UPPER && alpha > 0)) {
+                const double t = (-s->rc[k]) / alpha;
+                if (j < 0 || t < best) { best = t; j = k; }
+            }
+        }
+        if (j < 0) {
+            s->status = LPO_DUAL_UNBOUNDED;
+            break;
+        }
+        lpo_direction(s, j);
+        lpo_eta(s->d, m, r, s->e);
+        const int64_t leaving = s->basis[r];
+        lpo_log(s, r, j, leaving);
+        s->basis[r] = j;
+        s->var_state[leaving] = below ? VS_LOWER : VS_UPPER;
+        s->var_state[j] = VS_BASIC;
+        lpo_rank1_update(s->Binv, m, m, m, r, s->e, s->rowr);
+        lpo_bounded_update_bfs(s);
+    }
+    return s->status;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Primal-dual algorithm pieces (special_solvers.py:402-447); the outer loop is driven from Python
  * (oracle/oracle.py) because it rebuilds the restricted primal every outer iteration.
  * ---------------------------------------------------------------------------------------------- */

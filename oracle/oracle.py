@@ -342,6 +342,29 @@ class OracleBounded(OracleRevised):
         return self._result(status)
 
 
+class OracleDualBounded(OracleBounded):
+    """Restatement of the build's opt-in bounded-variable DUAL simplex (lpo_dual_bounded_solve): no counterpart in the
+    reference, whose bounded solver is the primal one and whose dual solver knows x >= 0 only -- parity unpinned by
+    nature; this is the checker of the GPU kernel's arithmetic, HiGHS the checker of its answers.  Infinite bounds stay
+    infinite (a free side can never be violated nor carry a nonbasic variable)."""
+
+    def __init__(self, c, A, b, lb, ub, basis, lb_nonbasic_vars, ub_nonbasic_vars, log_cap=1 << 16):
+        c32, A32, b32 = preprocess(c, A, b)
+        n = A32.shape[1]
+        vs = np.full(n, VS_EXCLUDED, dtype=np.int32)
+        vs[np.array(lb_nonbasic_vars).astype(int)] = VS_LOWER
+        vs[np.array(ub_nonbasic_vars).astype(int)] = VS_UPPER
+        OracleRevised.__init__(self, c, A, b, basis, kind="bounded", log_cap=log_cap, var_state=vs, check=False)
+        self.lb = np.array(lb, dtype=np.float64)
+        self.ub = np.array(ub, dtype=np.float64)
+        self._bind()
+        lib().lpo_bounded_update_bfs(C.byref(self.s))
+
+    def solve(self, maxiters=100):
+        status = lib().lpo_dual_bounded_solve(C.byref(self.s), int(maxiters))
+        return self._result(status)
+
+
 def bounds_on_bfs(A, b):
     """utils.py:20-40 in the reference's own scalar arithmetic."""
     m = A.shape[0]

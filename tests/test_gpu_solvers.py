@@ -571,3 +571,58 @@ def test_refine_every_keeps_a_long_run_exact():
     eng = s._engine
     Bm = np.asarray(A, dtype=np.float32).astype(np.float64)[:, eng.host_basis()]
     assert np.max(np.abs(Bm @ eng.host_Binv() - np.eye(256))) < 1e-11
+
+
+@pytest.mark.parametrize("m,seed", [(8, 0), (16, 1), (16, 5), (64, 2), (100, 6), (128, 3)])
+def test_bounded_variable_dual_simplex_opt_in(m, seed):
+    """BoundedVariableDualSimplexSolver (BASELINE config 5's wording; the reference has the bounded PRIMAL solver and a dual
+    solver for x >= 0 only, so this opt-in class is PARITY UNPINNED against it): one launch per solve() call.  Bit for
+    bit against the oracle's restatement of the same rules (lpo_dual_bounded_solve: pivot log, B^-1, x_B, per-variable
+    states, also when the solve is cut into re-entrant pieces), bounds and A x = b hold, and the optimum is HiGHS's."""
+    from scipy.optimize import linprog
+
+    from linprog_amd.special_solvers import BoundedVariableDualSimplexSolver
+    from oracle import oracle as O
+
+    args = gen.gen_box_dual(m, 2 * m, seed)
+    c, A, b, lb, ub = args[:5]
+    s = logged(BoundedVariableDualSimplexSolver)(*args)
+    o = O.OracleDualBounded(*args)
+    for k in (1, 3, 100000):
+        res, want = s.solve(k), o.solve(k)
+        eng = s._engine
+        assert s.pivot_log().tolist() == want.log.tolist() and res.iters == want.iters
+        assert res.basis.tolist() == want.basis.tolist()
+        assert np.array_equal(eng.host_Binv(), o.Binv) and np.array_equal(eng.host_xB(), o.xB)
+        assert np.array_equal(eng.host_var_state(), want.var_state) and np.array_equal(res.x, want.x)
+    assert res.optimum is True
+    A32, b32, c32 = (np.asarray(v, dtype=np.float32).astype(float) for v in (A, b, c))
+    assert np.abs(A32 @ res.x - b32).max() < 1e-9 and (res.x - lb).min() >= -1e-8 and (ub - res.x).min() >= -1e-8
+    hs = linprog(c32, A_eq=A32, b_eq=b32, bounds=list(zip(lb, [None if np.isinf(u) else u for u in ub])), method="highs")
+    assert hs.status == 0 and abs(res.cost - hs.fun) <= 1e-9 * max(1.0, abs(hs.fun))
+    # the bounded PRIMAL solver (the reference's own) reaches the same optimum from its own feasible start
+    from linprog_amd.special_solvers import BoundedVariablePrimalSimplexSolver
+
+    ubf = np.where(np.isinf(ub), 1e6, ub)
+    k = A.shape[1] - A.shape[0]
+    p = BoundedVariablePrimalSimplexSolver(c, A, b, lb, ubf, args[5], np.arange(k), np.array([], dtype=int)).solve(100000)
+    assert p.optimum and abs(p.cost - res.cost) <= 1e-7 * max(1.0, abs(res.cost))
+
+
+def test_bounded_variable_dual_simplex_errors():
+    """Dual infeasible start -> BasisIsDualInfeasibleError (dual_solvers.py:14-16 read for two bounds); an infeasible primal
+    -> DualIsUnboundedError out of solve() (:41-44); a state beyond one CU's LDS is refused at construction."""
+    from linprog_amd import exceptions
+    from linprog_amd.special_solvers import BoundedVariableDualSimplexSolver
+
+    c, A, b, lb, ub, basis, lo, up = gen.gen_box_dual(16, 32, 1)
+    with pytest.raises(exceptions.BasisIsDualInfeasibleError):
+        BoundedVariableDualSimplexSolver(c, A, b, lb, ub, basis, np.arange(16), np.array([], dtype=int))
+    b2 = b.copy()
+    b2[3] = -5.0  # row 3: G x + s = -5 with G, x, s >= 0 has no solution (preprocessing flips the row: -G x - s = 5)
+    s = BoundedVariableDualSimplexSolver(c, A, b2, lb, ub, basis, lo, up)
+    with pytest.raises(exceptions.DualIsUnboundedError):
+        s.solve(1000)
+    args = gen.gen_box_dual(170, 340, 0)
+    with pytest.raises(ValueError):
+        BoundedVariableDualSimplexSolver(*args)
