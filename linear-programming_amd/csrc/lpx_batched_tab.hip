@@ -39,17 +39,6 @@ __device__ __forceinline__ double tb_readlane(double v, int lane)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// x = fma(v[lane], p, x) with the readlanes and the fma pinned in program order: left to the compiler, the readlanes of a
-// whole unrolled column are issued first and the scalars they produce are spilled (v_writelane) and read back
-#define TB_FMA_LANE(xv, elo, ehi, LANE, p)                                                                               \
-    do {                                                                                                                \
-        int lo_, hi_;                                                                                                   \
-        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(lo_) : "v"(elo), "n"(LANE));                                    \
-        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(hi_) : "v"(ehi), "n"(LANE));                                    \
-        const double ei_ = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned)lo_)); \
-        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(xv) : "s"(ei_), "v"(p));                                            \
-    } while (0)
-
 struct TabBatchArgs {
     int64_t batch, m, n;
     const float *A, *b, *c;
@@ -209,8 +198,11 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
             for (int i = 0; i < MR; ++i) x[i] = -0.0;
         }
         {
-            const long long eb = __double_as_longlong(e);
-            const int elo = (int)(eb & 0xffffffffLL), ehi = (int)(eb >> 32);
+            // e_i lives in lane i; E[g] holds row g of the wave's four 16-lane rows in every row, so that row i's
+            // multiplier reaches all 64 lanes as a DPP row broadcast inside the fma itself: ONE VALU instruction per element
+            // (two v_readlane_b32 + v_fmac_f64 before: 3.1 -> see DESIGN.md section 5)
+            double E[4];
+            lpx_rows_bcast(e, E);
             const int rchunk = r >> 3;
 #pragma unroll
             for (int c = 0; c < MR / 8; ++c) {
@@ -219,7 +211,7 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
                     for (int j = 0; j < 8; ++j) x[8 * c + j] = (8 * c + j == r) ? -0.0 : x[8 * c + j];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) TB_FMA_LANE(x[8 * c + j], elo, ehi, 8 * c + j, prs);
+                for (int j = 0; j < 8; ++j) LPX_FMAC_ROW_BCAST(x[8 * c + j], E[(8 * c + j) / 16], prs, (8 * c + j) % 16);
             }
         }
         rc = fma(em, prs, mine ? -0.0 : rc);
@@ -618,8 +610,8 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
         const int rlm = (rg == rr) ? rl : -1;
         {
             const double ew = es[r0 + lane]; // lane i of every wave of the row group holds e of its row i
-            const long long eb = __double_as_longlong(ew);
-            const int elo = (int)(eb & 0xffffffffLL), ehi = (int)(eb >> 32);
+            double E[4]; // ... and E[g] row g of those 64 in all four 16-lane rows: the fma broadcasts from there (k_batched_tab)
+            lpx_rows_bcast(ew, E);
             const int rchunk = rlm >> 3; // only the 8 rows around the pivot row pay for the selects: a scalar branch
 #pragma unroll
             for (int c = 0; c < MRL / 8; ++c) {
@@ -628,7 +620,7 @@ __global__ __launch_bounds__(64 * RW * CW, MRL <= 32 ? 4 : 3) void k_batched_tab
                     for (int j = 0; j < 8; ++j) x[8 * c + j] = (8 * c + j == rlm) ? -0.0 : x[8 * c + j];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) TB_FMA_LANE(x[8 * c + j], elo, ehi, 8 * c + j, prs);
+                for (int j = 0; j < 8; ++j) LPX_FMAC_ROW_BCAST(x[8 * c + j], E[(8 * c + j) / 16], prs, (8 * c + j) % 16);
             }
         }
         rc = fma(em, prs, mine ? -0.0 : rc);

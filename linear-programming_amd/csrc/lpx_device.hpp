@@ -123,6 +123,30 @@ __device__ __forceinline__ T wave_allreduce(T v, Op op)
     return op(a, b);
 }
 
+// x += v[lane N of the lane's own row of 16 lanes] * p: the one DPP control the 64-bit VALU ops of gfx90a+ accept
+// (row_newbcast).  One VALU instruction where a scalar broadcast costs two v_readlane_b32 and the fma; same issue rate
+// as a plain v_fmac_f64 (tools/fma_rate.hip).  Every lane of the wave must be active, and `v` must have been written at
+// least two wait states earlier (lpx_rows_bcast ends with them).
+template <int N>
+__device__ __forceinline__ void lpx_fmac_row_bcast(double &x, double v, double p)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(v), "v"(p), "n"(N));
+}
+// the same for a lane index that is an unrolled loop's variable (a template argument must be a constant expression at
+// parse time, an "n" operand only once the loop is unrolled)
+#define LPX_FMAC_ROW_BCAST(x, v, p, N) \
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(v), "v"(p), "n"(N))
+// E[g][lane] = v[16 g + lane % 16]: row g of the wave's 16-lane rows copied to all four rows -- three lane swaps per
+// dword (v_permlane32_swap, then v_permlane16_swap on each half), the operand layout lpx_fmac_row_bcast broadcasts from
+__device__ __forceinline__ void lpx_rows_bcast(double v, double (&E)[4])
+{
+    double lo, hi;
+    lpx_lane_swap<double, true>(v, lo, hi);      // lo = rows (0, 1, 0, 1), hi = rows (2, 3, 2, 3)
+    lpx_lane_swap<double, false>(lo, E[0], E[1]); // rows (0, 0, 0, 0), (1, 1, 1, 1)
+    lpx_lane_swap<double, false>(hi, E[2], E[3]);
+    asm volatile("s_nop 1" : "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])); // VALU write -> DPP read of the same VGPR
+}
+
 __device__ __forceinline__ VI wave_argmin(VI a)
 {
     return wave_allreduce(a, [](VI x, VI y) { return vi_less(y.v, y.i, x.v, x.i) ? y : x; });

@@ -29,13 +29,12 @@ __device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, 
 }
 #endif
 
-// x += e_N * pr with e_N taken from lane N of the lane's own row of 16 lanes (DPP row_newbcast, the one DPP control the
-// 64-bit VALU ops of gfx90a+ accept): the 16 multipliers of a group sit one per lane, no scalar loads, no readlanes.
-// Same issue rate as a plain v_fmac_f64 (tools/fma_rate.hip).
+// x += e_N * pr with e_N taken from lane N of the lane's own row of 16 lanes (lpx_device.hpp, lpx_fmac_row_bcast): the 16
+// multipliers of a group sit one per lane, no scalar loads, no readlanes
 template <int N>
 __device__ __forceinline__ void tb_fmac_bcast(double &x, double e16, double pr)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(e16), "v"(pr), "n"(N));
+    lpx_fmac_row_bcast<N>(x, e16, pr);
 }
 template <int N>
 __device__ __forceinline__ double tb_bcast(double e16)
