@@ -325,6 +325,25 @@ int lpx_tableau_block_begin(const lpx_tableau *s, void *stream);
 int lpx_tableau_block_propose(const lpx_tableau *s, int64_t pending, double *sendbuf, void *stream);
 int lpx_tableau_block_commit(const lpx_tableau *s, int64_t pending, const double *recvbuf, int64_t nranks, void *stream);
 int lpx_tableau_block_flush(const lpx_tableau *s, int64_t block, void *stream);
+/* The whole column-partitioned loop as ONE call per chunk of pivots, the collective included: liblpx links RCCL and
+ * enqueues, for each of `iters` pivots, propose -> ncclAllGather of the ranks' proposals (lpx_tableau_msg_len(m) doubles
+ * each, over xGMI) -> commit, plus the passes over this rank's slice, all on `stream` (slices for which
+ * lpx_tableau_pipelined() holds: the passes and the next block's pivots side by side on streams of the library's own, the
+ * collective with the pivots) -- nothing returns to the host between two pivots, the host reads the control block once per
+ * call as for the unpartitioned loop.  Same decisions and bits as the lpx_tableau_block_* sequence above
+ * (primal_solvers.py:135-167, :247-253); no counterpart in the reference, which is single-process.
+ *   comm     an RCCL communicator over the ranks that hold the slices: lpx_dist_unique_id on one rank, its 128 bytes
+ *            handed to the others by any means, lpx_dist_comm_create on every rank (or a caller's own ncclComm_t)
+ *   block    8, 16 or 32, THE SAME ON EVERY RANK (see lpx_tableau_block_*)
+ *   sendbuf  lpx_tableau_msg_len(m) doubles, recvbuf nranks times that (device memory, the caller's)
+ * lpx_tableau_dual_dist_iterate: the dual rules (dual_solvers.py:47-108), passes in place. */
+int lpx_dist_unique_id(void *id128);
+int lpx_dist_comm_create(const void *id128, int64_t nranks, int64_t rank, void **comm);
+int lpx_dist_comm_destroy(void *comm);
+int lpx_tableau_dist_iterate(const lpx_tableau *s, void *comm, int64_t nranks, int64_t iters, int64_t block, double *sendbuf,
+                             double *recvbuf, void *stream);
+int lpx_tableau_dual_dist_iterate(const lpx_tableau *s, void *comm, int64_t nranks, int64_t iters, int64_t block,
+                                  double *sendbuf, double *recvbuf, void *stream);
 /* The same for the dual rules (dual_solvers.py:47-108; message layout of lpx_tableau_dual_propose): every rank picks the
  * leaving row from its replica of x_B, proposes (theta, variable, column as the pending updates leave it); the commit takes
  * the first argmin of theta over the ranks.  Flush with lpx_tableau_block_flush. */

@@ -99,6 +99,11 @@ _SIGS = {
     "lpx_tableau_block_propose": (C.c_int, [C.POINTER(LpxTableau), i64, vp, vp]),
     "lpx_tableau_block_commit": (C.c_int, [C.POINTER(LpxTableau), i64, vp, i64, vp]),
     "lpx_tableau_block_flush": (C.c_int, [C.POINTER(LpxTableau), i64, vp]),
+    "lpx_dist_unique_id": (C.c_int, [vp]),
+    "lpx_dist_comm_create": (C.c_int, [vp, i64, i64, C.POINTER(vp)]),
+    "lpx_dist_comm_destroy": (C.c_int, [vp]),
+    "lpx_tableau_dist_iterate": (C.c_int, [C.POINTER(LpxTableau), vp, i64, i64, i64, vp, vp, vp]),
+    "lpx_tableau_dual_dist_iterate": (C.c_int, [C.POINTER(LpxTableau), vp, i64, i64, i64, vp, vp, vp]),
     "lpx_tableau_dual_block_begin": (C.c_int, [C.POINTER(LpxTableau), vp]),
     "lpx_tableau_dual_block_propose": (C.c_int, [C.POINTER(LpxTableau), i64, vp, vp]),
     "lpx_tableau_dual_block_commit": (C.c_int, [C.POINTER(LpxTableau), i64, vp, i64, vp]),

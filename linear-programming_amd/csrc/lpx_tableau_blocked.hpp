@@ -281,8 +281,20 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         double di = 0.0;
         if (c.var != LPX_NOIDX) { // workgroup-uniform
             const double rv = (l32 < P) ? a.b.R[l32 * a.b.ldr + slot] : 0.0;
+            const double rvo = (OLD && l32 < PO) ? a.o.R[l32 * a.o.ldr + slot] : 0.0;
             di = inm ? s.T[i * s.ld + slot] : 0.0;
-            di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
+            if constexpr (OLD) { // the pipelined chain's 2 KB multipliers pass through two chunks of registers (see below)
+                di = tb_column_chain<TB_CH, 0>(di, PO, (int)slot, (int)i, svo, pvo, ea, rvo, cond);
+                TB_LOADS_STAY_BELOW();
+                tb_ld_chunk<0>(ea, Eti, a.b.lde, P, true);
+                di = tb_column_chain<TB_CH, TB_CH>(di, PO, (int)slot, (int)i, svo, pvo, eb, rvo, cond);
+                TB_LOADS_STAY_BELOW();
+                tb_ld_chunk<TB_CH>(eb, Eti, a.b.lde, P, true);
+                di = tb_column_chain<TB_CH, 0>(di, P, (int)slot, (int)i, sv, pv, ea, rv, cond);
+                di = tb_column_chain<TB_CH, TB_CH>(di, P, (int)slot, (int)i, sv, pv, eb, rv, cond);
+            } else {
+                di = tb_column_chain(di, P, (int)slot, (int)i, sv, pv, e, rv, cond);
+            }
         }
         if (inm) a.sendbuf[2 + i] = di;
         return;

@@ -155,8 +155,10 @@ class TableauEngine:
         self.T_alt = None
         if group is None and T.numel() * 8 <= self.FUSED_MAX_BYTES:
             self.T_alt = torch.zeros_like(T)
-        elif (group is None and not self.dual and self.PIPELINE_MIN_BYTES is not None
-              and 8 * (self.m + 1) * (self.n + 1) >= self.PIPELINE_MIN_BYTES):
+        elif (not self.dual and self.PIPELINE_MIN_BYTES is not None
+              and 8 * (self.m + 1) * (self.n + 1) >= self.PIPELINE_MIN_BYTES
+              and (group is None or (slot_var is not None and self._c_loop_wanted(group)))):
+            # (a column-partitioned slice is pipelined by the library's own loop only: lpx_tableau_dist_iterate)
             self.T_alt = torch.zeros_like(T)
         s.T_alt = None if self.T_alt is None else self.T_alt.data_ptr()
         _lib.check(self.lib.lpx_ctrl_init(s.ctrl, int(f32_phase), stream_ptr()))
@@ -175,6 +177,38 @@ class TableauEngine:
             t = torch.tensor([self.kb], dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             self.kb = int(t.item())
+            # the library's own loop around RCCL (lpx.h, lpx_tableau_dist_iterate): a communicator of liblpx's own over the
+            # same ranks -- rank 0's unique id travels through the process group once
+            self.dist_comm = None
+            if self._c_loop_wanted(group):
+                rank = dist.get_rank(group)
+                ident = (C.c_char * 128)()
+                if rank == 0:
+                    _lib.check(self.lib.lpx_dist_unique_id(ident))
+                box = [bytes(ident.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+                comm = C.c_void_p()
+                _lib.check(self.lib.lpx_dist_comm_create(box[0], self.nranks, rank, C.byref(comm)))
+                self.dist_comm = comm
+
+    #: column-partitioned loops over RCCL run inside liblpx (one C call per chunk of pivots); "0": the Python loop around
+    #: lpx_tableau_block_* and torch.distributed's all-gather (what the gloo rehearsals run)
+    C_LOOP = os.environ.get("LPX_DIST_C_LOOP", "1") != "0"
+
+    @classmethod
+    def _c_loop_wanted(cls, group):
+        import torch.distributed as dist
+
+        return cls.C_LOOP and group is not None and dist.get_backend(group) == "nccl"
+
+    def __del__(self):
+        comm = getattr(self, "dist_comm", None)
+        if comm is not None:
+            try:
+                self.lib.lpx_dist_comm_destroy(comm)
+            except Exception:
+                pass
+            self.dist_comm = None
 
     # ------------------------------------------------------------------ construction from a host problem
     @classmethod
@@ -256,6 +290,12 @@ class TableauEngine:
             return
         ex = self.exchange
         iters = int(iters)
+        if self.kb > 0 and iters > 0 and getattr(self, "dist_comm", None) is not None:
+            # large slices over RCCL: the whole chunk of pivots, collectives included, in ONE call (lpx_tableau_dist_iterate)
+            f = self.lib.lpx_tableau_dual_dist_iterate if self.dual else self.lib.lpx_tableau_dist_iterate
+            _lib.check(f(C.byref(self.s), self.dist_comm, self.nranks, iters, self.kb, ex.sendbuf.data_ptr(),
+                         ex.recvbuf.data_ptr(), st))
+            return
         if self.dual:
             kb = self.kb
             if kb > 0 and iters > 0:  # large slices: deferred updates (lpx.h, lpx_tableau_dual_block_*)
@@ -339,7 +379,8 @@ class TableauEngine:
         # every call starts by re-reading the reduced-cost row and x_B from T and ends with a pass over T
         kb = self.kb if self.group is not None else int(self.lib.lpx_tableau_block_size(C.byref(self.s)))
         chunk, first_chunk = (8 * kb, kb) if kb > 0 else (self.CHUNK, self.FIRST_CHUNK)
-        if kb > 0 and self.group is None and not self.dual and self.lib.lpx_tableau_pipelined(C.byref(self.s)):
+        if kb > 0 and not self.dual and self.lib.lpx_tableau_pipelined(C.byref(self.s)) and (
+                self.group is None or getattr(self, "dist_comm", None) is not None):
             # pipelined chain: the first and the last block of a call overlap with nothing, so calls are long
             chunk, first_chunk = 32 * kb, 2 * kb
         while left > 0:

@@ -310,7 +310,14 @@ def main_dual(mode, m, n, seed, maxiters):
 def main():
     mode = sys.argv[1]
     m, n, seed, maxiters = (int(v) for v in sys.argv[2:6])
-    dist.init_process_group("gloo")
+    # LPX_TEST_BACKEND=nccl (one rank per GPU: world size 1 on a one-GPU box): the library's own loop around RCCL
+    # (lpx_tableau_dist_iterate) instead of the Python loop around torch.distributed that the gloo rehearsals run
+    backend = os.environ.get("LPX_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if mode.endswith("-dual"):
         main_dual(mode, m, n, seed, maxiters)
@@ -339,6 +346,14 @@ def main():
             kbs = [None] * world
             dist.all_gather_object(kbs, s._engine.kb)
             assert len(set(kbs)) == 1 and kbs[0] == int(os.environ["LPX_TABLEAU_BLOCK"]), f"ranks disagree on the block: {kbs}"
+        if os.environ.get("LPX_TEST_BACKEND") == "nccl":  # the library's own loop is what runs, pipelined where asked for
+            import ctypes as C
+
+            from linprog_amd import _lib
+
+            assert s._engine.dist_comm is not None and s._engine.kb == int(os.environ["LPX_TABLEAU_BLOCK"])
+            want_pipe = os.environ.get("LPX_TABLEAU_PIPELINE_MIN_MB") == "0" and cls.CONDENSED
+            assert bool(_lib.load().lpx_tableau_pipelined(C.byref(s._engine.s))) == want_pipe
         res = s.solve(maxiters)
         assert s.pivot_log().tolist() == want.log.tolist(), f"rank {rank}: pivot sequence differs"
         assert res.basis.tolist() == want.basis.tolist() and res.optimum == (want.status == O.OPTIMAL)

@@ -80,6 +80,20 @@ def test_product_path_ranks_agree_on_one_block_size():
     _run("gpu", 3, 50, 121, 2, 100000, LPX_TEST_RAGGED_KB="1", LPX_TABLEAU_BLOCK="16")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,env", [
+    ("gpu", {"LPX_TABLEAU_BLOCK": "8"}), ("gpu", {"LPX_TABLEAU_BLOCK": "32", "LPX_TABLEAU_PIPELINE_MIN_MB": "0"}),
+    ("gpu", {"LPX_TABLEAU_BLOCK": "16", "LPX_TABLEAU_PIPELINE_MIN_MB": "0", "LPX_TB_PIPE_CUS": "0"}),
+    ("gpu", {"LPX_TABLEAU_BLOCK": "16", "LPX_TABLEAU_CONDENSED": "0"}), ("gpu-dual", {"LPX_TABLEAU_BLOCK": "8"}),
+    ("gpu-dual", {"LPX_TABLEAU_BLOCK": "32", "LPX_TABLEAU_CONDENSED": "0"})],
+    ids=lambda v: ",".join(f"{k[4:]}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_library_loop_over_rccl_one_rank(mode, env):
+    """lpx_tableau_dist_iterate / lpx_tableau_dual_dist_iterate: propose -> ncclAllGather -> commit for every pivot and the
+    passes over the slice, enqueued by liblpx itself over a communicator of its own -- world size 1 (RCCL refuses two ranks
+    on one GPU), in-place and pipelined chains, both layouts, primal and dual: the oracle's pivot sequences."""
+    _run(mode, 1, 64, 128, 2, 100000, LPX_TABLEAU_BLOCK_MIN_MB="0", LPX_TEST_BACKEND="nccl", **env)
+
+
 @pytest.mark.parametrize("nproc,m,n", [(2, 16, 32), (3, 24, 50)])
 def test_dual_protocol_cpu_gloo(nproc, m, n):
     _run("cpu-dual", nproc, m, n, 1, 100000)
