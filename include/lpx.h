@@ -200,7 +200,9 @@ int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *str
  * lpx_revised_small_lds_bytes(m, n, kind) <= 158 KiB says whether a shape fits (m <= 128 at n = 2m), else LPX_E_SIZE.
  * Dot products are accumulated in index order with fma: bit-identical to the oracle's loops.
  * lpx_revised_solve_small_batch: `batch` such states (a DEVICE array of lpx_revised, all m x n), one workgroup each; x
- * (batch x n) and cost (batch) receive the expanded solutions when non-NULL (special_solvers.py:201-206 for bounded). */
+ * (batch x n) and cost (batch) receive the expanded solutions when non-NULL (special_solvers.py:201-206 for bounded).
+ * Every state's control block must be RUNNING (lpx_ctrl_begin_solve per LP): a workgroup whose LP is in any other state
+ * returns at once and leaves that LP's rows of x and cost UNTOUCHED (stale, not zeroed). */
 int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind);
 int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t maxiters, void *stream);
 int lpx_revised_solve_small_batch(const lpx_revised *dev_states, int64_t batch, int64_t m, int64_t n, int kind,
@@ -473,7 +475,9 @@ int lpx_pivot_update(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t 
  * (LPX_STATIC_ROW_MAX = 65536 doubles = 512 KiB per GPU, held until the process ends); the call allocates nothing, on
  * the device or through any library.  Same kernels and the same bits as lpx_pivot_update.  ld > 65536 returns
  * LPX_E_SIZE (use lpx_pivot_update then).  All calls on one GPU share the array: calls that overlap on one GPU (two
- * streams, two host threads) race on it -- serialise them on one stream. */
+ * streams, two host threads) race on it -- serialise them on one stream.  The array used is the copy on the GPU that owns
+ * M (not the current device); the FIRST call per GPU looks its address up (hipGetSymbolAddress) and is not safe inside
+ * stream capture: make one call per GPU outside capture first. */
 #define LPX_STATIC_ROW_MAX 65536
 int lpx_pivot_update_static(double *M, int64_t rows, int64_t cols, int64_t ld, int64_t r, const double *e, void *stream);
 /* Eta column, primal_solvers.py:235-244: e_i = (-d_i)/d_r, e_r = 1/d_r. */

@@ -1520,15 +1520,29 @@ static __device__ __align__(256) double scratch[LPX_STATIC_ROW_MAX];
 static std::mutex g_static_mu;
 static double *g_static_row[LPX_STATIC_MAX_DEVICES];
 
-static int static_row_scratch(double **out)
+// The array exists once per GPU, each copy at its own address: the copy that belongs to a call is the one on the device
+// that owns M (hipPointerGetAttributes), not whatever device happens to be current.  The first call per device looks the
+// address up (hipGetSymbolAddress, with that device current) and is therefore NOT capture-safe: make one call per device
+// outside stream capture first (lpx.h).
+static int static_row_scratch(const void *M, double **out)
 {
-    int dev = -1;
-    LPX_HIP(hipGetDevice(&dev));
+    int cur = -1;
+    LPX_HIP(hipGetDevice(&cur));
+    int dev = cur;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, M) == hipSuccess && attr.type == hipMemoryTypeDevice) dev = attr.device;
+    else (void)hipGetLastError();
     LPX_REQUIRE(dev >= 0 && dev < LPX_STATIC_MAX_DEVICES, "device index beyond the per-device table");
     std::lock_guard<std::mutex> lock(g_static_mu);
     if (g_static_row[dev] == nullptr) {
         void *p = nullptr;
-        LPX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (dev != cur) LPX_HIP(hipSetDevice(dev));
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (dev != cur) (void)hipSetDevice(cur);
+        if (e != hipSuccess) {
+            lpx_set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return LPX_E_HIP;
+        }
         LPX_REQUIRE(p != nullptr && lpx_aligned16(p), "static scratch has no usable device address");
         g_static_row[dev] = (double *)p;
     }
@@ -1550,7 +1564,7 @@ extern "C" int lpx_pivot_update_static(double *M, int64_t rows, int64_t cols, in
         return LPX_E_SIZE;
     }
     double *rowr = nullptr;
-    int rc = static_row_scratch(&rowr);
+    int rc = static_row_scratch(M, &rowr);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     // the whole row of the last call's contents that this call reads is overwritten first: nothing to clear

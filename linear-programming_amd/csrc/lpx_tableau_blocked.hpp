@@ -53,8 +53,11 @@ __device__ __forceinline__ double tb_apply(double x, bool is_slot, bool is_row, 
 // -DLPX_TB_STAMPS: diagnostic build, workgroup 0 prints where the two per-pivot kernels spend their time (10 ns ticks)
 #ifdef LPX_TB_STAMPS
 __device__ long long g_tb_stamp[2][16];
+__device__ long long g_tb_wgend[2][4096]; // every workgroup's last instruction: how long is a kernel's tail beyond workgroup 0?
 #define LPX_TB_STAMP(k, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tb_stamp[k][n] = (long long)wall_clock64(); } while (0)
+#define LPX_TB_WGEND(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_tb_wgend[k][blockIdx.x] = (long long)wall_clock64(); } while (0)
 #else
+#define LPX_TB_WGEND(k) do { } while (0)
 #define LPX_TB_STAMP(k, n) do { } while (0)
 #endif
 
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_column(TbArgs a)
         a.b.xbest[blockIdx.x] = none ? 0.0 : t.xv;
     }
     LPX_TB_STAMP(0, 6);
+    LPX_TB_WGEND(0);
 }
 
 // leaving row, eta column, x_B, the pivot row as the pending updates leave it, the reduced-cost row and its pricing
@@ -521,6 +525,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tb_prepare(TbArgs a)
         g_tb_stamp[1][8] = (long long)wall_clock64();
         if (ctrl->pivots >= 96 && ctrl->pivots < 160 && (P == 0 || P == 15 || P == 31)) {
             const long long *c0 = g_tb_stamp[0], *p0 = g_tb_stamp[1];
+            long long cmax = 0;
+            for (int64_t k = 0; k < a.nratio && k < 4096; ++k) cmax = g_tb_wgend[0][k] > cmax ? g_tb_wgend[0][k] : cmax;
+            printf("P=%d column tail beyond workgroup 0: %lld, boundary after the last workgroup: %lld | ", P, cmax - c0[6], p0[0] - cmax);
             printf("P=%d column: status %lld | partials %lld | price reduce %lld | column+chain %lld | ratio reduce %lld | end %lld || "
                    "gap %lld || prepare: status %lld | partials %lld | ratio reduce %lld | payload %lld | eta %lld | row chain %lld | "
                    "rc+price reduce %lld | books %lld\n", P, c0[1] - c0[0], c0[2] - c0[1], c0[3] - c0[2], c0[4] - c0[3], c0[5] - c0[4],

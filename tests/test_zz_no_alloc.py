@@ -20,12 +20,18 @@ def _both(torch, lib, L, rows, cols, pad, seed):
     scr = torch.zeros(ld + 2, dtype=torch.float64, device="cuda")
     lib.check(L.lpx_pivot_update(want.data_ptr(), rows, cols, ld, r, ed.data_ptr(), scr.data_ptr(), None))
     got = torch.from_numpy(M).cuda()
+    warm = torch.from_numpy(M).cuda()
+    # one warm-up call: the symbol look-up and the module load happen once per device; then the DRIVER's free-memory
+    # figure (hipMemGetInfo -- torch.cuda.memory_allocated() only sees torch's own caching allocator, a hipMalloc inside
+    # liblpx would not move it) must not change across a call
+    lib.check(L.lpx_pivot_update_static(warm.data_ptr(), rows, cols, ld, r, ed.data_ptr(), None))
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    before, before_torch = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated()
     lib.check(L.lpx_pivot_update_static(got.data_ptr(), rows, cols, ld, r, ed.data_ptr(), None))
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == before and torch.cuda.memory_allocated() == before_torch
     assert np.array_equal(got.cpu().numpy()[:, :cols], want.cpu().numpy()[:, :cols])
+    assert np.array_equal(warm.cpu().numpy()[:, :cols], want.cpu().numpy()[:, :cols])
 
 
 def test_static_pivot_update_matches_pivot_update_twice():
