@@ -183,7 +183,9 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     if blocks and kb not in (0, PPS):
         PPS = kb
     pipelined = bool(kb) and group is None and bool(lib.lpx_tableau_pipelined(C.byref(eng.s)))
-    one_launch = kb == 0 and eng.T_alt is not None and os.environ.get("LPX_TABLEAU_FUSED", "1") != "0"
+    chain_kind = int(lib.lpx_tableau_chain_kind(C.byref(eng.s))) if group is None else -1
+    small_chain = chain_kind == _lib.CHAIN_SMALL
+    one_launch = chain_kind == _lib.CHAIN_FUSED
     K_piv, W_piv = K * PPS, W * PPS
 
     def barrier():
@@ -248,6 +250,8 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     # roofline of the update kernel on THIS rank's slice: algorithmic bytes = 16 B x (m+1) x (n_local+1) per launch
     n_loc = j1 - j0
     bytes_per_launch = 16.0 * (m + 1) * (n_loc + 1)
+    if k1_n.value == 0:
+        sys.exit("bench invalid: no launch of the update kernel was timed")
     k1_avg_s = (k1_ms.value / 1e3) / max(1, k1_n.value)
     achieved = bytes_per_launch / k1_avg_s / 1e9
     traffic = traffic_src = None
@@ -287,12 +291,17 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
                    "chain": ("pipelined: the pass of block k streams T -> T_alt (and back) on the CUs of one stream while block "
                              "k+1 is decided on the CUs of another from the buffer the pass reads plus the pending pairs of "
                              "both blocks (chains of up to 64)") if pipelined
-                   else ("in place: decisions, then the pass" if kb else "one update per pivot"),
+                   else ("in place: decisions, then the pass" if kb else
+                         "one launch per block of 8 pivots: one workgroup decides the block (rows' multipliers and columns' "
+                         "pivot-row entries in registers, exchanges through LDS) while the other workgroups apply the previous "
+                         "block, two buffers" if small_chain else "one update per pivot"),
                    "pivots_per_step": PPS, "pivots_timed": K_piv, "us_per_pivot": dt / K_piv * 1e6,
-                   "launches_per_pivot": ((2 if group is None else 3) + 1.0 / kb) if kb else (1 if one_launch else 3),
+                   "launches_per_pivot": ((2 if group is None else 3) + 1.0 / kb) if kb else (0.125 if small_chain else
+                                                                                                  1 if one_launch else 3),
                    "partition": f"columns/{world}",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_tb_flush2 (the pass that applies a block of pending rank-1 updates)" if kb
+                     else "k_tb_small (one workgroup decides 8 pivots, the others apply the previous 8: T -> T_alt)" if small_chain
                      else "k_t_fused (update + next pivot's pricing / column / ratio test, two buffers)"
                      if one_launch else "k_rank1<tableau>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -17,6 +17,7 @@ RUNNING, OPTIMAL, PRIMAL_UNBOUNDED, DUAL_UNBOUNDED, NOT_NONBASIC = 0, 1, 2, 3, 4
 VS_BASIC, VS_LOWER, VS_UPPER, VS_EXCLUDED = 0, 1, 2, 3
 PRICE_FIRST_NEGATIVE, PRICE_DANTZIG = 0, 1
 RATIO_TEXTBOOK, RATIO_HARRIS = 0, 1
+CHAIN_EAGER, CHAIN_FUSED, CHAIN_SMALL, CHAIN_DEFERRED, CHAIN_PIPELINED = 0, 1, 2, 3, 4
 KIND_PRIMAL, KIND_DUAL, KIND_BOUNDED, KIND_PRIMAL_NAIVE, KIND_DUAL_NAIVE, KIND_DUAL_BOUNDED = 0, 1, 2, 3, 4, 5
 
 vp = C.c_void_p
@@ -91,6 +92,7 @@ _SIGS = {
     "lpx_tableau_msg_len": (i64, [i64]),
     "lpx_tableau_block_size": (i64, [C.POINTER(LpxTableau)]),
     "lpx_tableau_pipelined": (C.c_int, [C.POINTER(LpxTableau)]),
+    "lpx_tableau_chain_kind": (C.c_int, [C.POINTER(LpxTableau)]),
     "lpx_tableau_propose": (C.c_int, [C.POINTER(LpxTableau), vp, C.c_int, vp]),
     "lpx_tableau_commit": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp]),
     "lpx_tableau_commit_begin": (C.c_int, [C.POINTER(LpxTableau), vp, i64, vp, vp]),

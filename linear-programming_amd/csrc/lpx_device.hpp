@@ -109,13 +109,19 @@ __device__ __forceinline__ void lpx_lane_swap(T v, T &a, T &b)
     __builtin_memcpy(&a, &ua, sizeof(T));
     __builtin_memcpy(&b, &ub, sizeof(T));
 }
+// every lane ends with the combination of its own row of 16 lanes
 template <typename T, typename Op>
-__device__ __forceinline__ T wave_allreduce(T v, Op op)
+__device__ __forceinline__ T row16_allreduce(T v, Op op)
 {
     v = op(v, lpx_dpp_move<T, LPX_DPP_QUAD_XOR1>(v));
     v = op(v, lpx_dpp_move<T, LPX_DPP_QUAD_XOR2>(v));
     v = op(v, lpx_dpp_move<T, LPX_DPP_ROW_ROR4>(v));
-    v = op(v, lpx_dpp_move<T, LPX_DPP_ROW_ROR8>(v));
+    return op(v, lpx_dpp_move<T, LPX_DPP_ROW_ROR8>(v));
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_allreduce(T v, Op op)
+{
+    v = row16_allreduce(v, op);
     T a, b;
     lpx_lane_swap<T, false>(v, a, b);
     v = op(a, b);

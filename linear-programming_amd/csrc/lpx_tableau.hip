@@ -15,6 +15,8 @@
 #include "lpx_graph.hpp"
 
 #include "lpx_tableau_blocked_decl.hpp"
+#include "lpx_tableau_dev.hpp"
+#include "lpx_tableau_small_decl.hpp"
 
 #include <rccl/rccl.h>
 
@@ -150,36 +152,6 @@ static int check_tableau(const lpx_tableau *s)
 // element and pivot for nothing.  Column slot k holds variable slot_var[k]; var_slot[] is the inverse map (-1: not in a
 // slot of this rank).  On a pivot the entering variable's slot takes over the leaving variable, whose column is the eta
 // column e itself (unit vector e_r updated: 0 + e_i * 1), written by K1 where the full form writes the new unit vector.
-__device__ __forceinline__ int64_t t_var(const lpx_tableau &s, int64_t slot) { return s.slot_var ? s.slot_var[slot] : s.col0 + slot; }
-// local column of variable j, -1 if this rank does not hold it
-__device__ __forceinline__ int64_t t_slot(const lpx_tableau &s, int64_t j)
-{
-    if (s.var_slot) return s.var_slot[j];
-    const int64_t k = j - s.col0;
-    return (k < 0 || k >= s.n) ? -1 : k;
-}
-// bookkeeping of a basis change (single thread): the full form flips var_state, the condensed form hands the slot over
-// It leaves ctrl->enter_slot = the local column that the update rewrites as a whole (full form: the entering variable's,
-// which becomes a unit vector; condensed: the slot handed to the leaving variable, which receives the eta column), -1 if
-// that column is not on this rank.  K1 reads it with the rest of the control block (no lookup through var_slot in
-// front of its 10^5..10^6 short workgroups).
-__device__ __forceinline__ void t_swap_columns(const lpx_tableau &s, int64_t j, int64_t leaving)
-{
-    if (s.slot_var) {
-        const int64_t k = s.var_slot[j];
-        if (k >= 0) {
-            s.slot_var[k] = leaving;
-            s.var_slot[leaving] = k;
-        }
-        s.var_slot[j] = -1;
-        s.ctrl->enter_slot = k;
-        return;
-    }
-    const int64_t ll = leaving - s.col0, jl = j - s.col0;
-    if (ll >= 0 && ll < s.n) s.var_state[ll] = LPX_VS_LOWER;
-    if (jl >= 0 && jl < s.n) s.var_state[jl] = LPX_VS_BASIC;
-    s.ctrl->enter_slot = (jl >= 0 && jl < s.n) ? jl : -1;
-}
 __device__ __forceinline__ int64_t t_unit_col(const lpx_tableau &s) { return s.ctrl->enter_slot; }
 
 // K3 (tableau): scan the carried reduced-cost row: one partial (min rc, first global column with rc<0) per
@@ -609,16 +581,6 @@ struct TfRatio {
     int64_t bv;   // its basic variable
     double dmax;  // max of the entering column
 };
-__device__ __forceinline__ int64_t tf_readlane_i64(int64_t v, int lane)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffLL), lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
-    return (int64_t)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double tf_readlane_f64(double v, int lane)
-{
-    return __longlong_as_double(tf_readlane_i64(__double_as_longlong(v), lane));
-}
 __device__ __forceinline__ TfRatio tf_ratio_op(TfRatio x, TfRatio y);
 // Wave reduction of ratio records whose row indices ASCEND with the lane (lanes without a row hold th = +inf, i = NOIDX
 // and come last): the first lane attaining the wave's minimum ratio is the first argmin (np.argmin, primal_solvers.py:166),
@@ -1675,6 +1637,58 @@ static int tableau_iterate_pipelined(const lpx_tableau *s, const TabWs &w, int64
     return LPX_OK;
 }
 
+// ---- launch-bound tableaus (lpx_tableau_small.hpp): one launch per block of TS_KB pivots -- workgroup 0 decides block k
+// while the other workgroups apply block k-1 (T_old -> T_new).  Buffers and the closing copy-back as in the pipelined chain.
+static inline bool t_use_small(const lpx_tableau *s)
+{
+    if (s->T_alt == nullptr || s->T_alt == s->T || lpx_env_int("LPX_TABLEAU_SMALL_CHAIN", 1) == 0) return false;
+    if (!(s->slot_var != nullptr || (s->col0 == 0 && s->n_global == s->n))) return false;
+    return s->m + 1 <= TS_THREADS && lpx_roundup(s->n + 1, 2) <= TS_THREADS && s->ratio_rule == LPX_RATIO_TEXTBOOK;
+}
+static int tableau_iterate_small(const lpx_tableau *s, const TabWs &w, int64_t iters, hipStream_t st)
+{
+    LPX_REQUIRE(lpx_aligned16(s->T_alt), "T_alt must be 16-byte aligned");
+    constexpr int KB = TS_KB;
+    const int64_t nb = lpx_cdiv(iters, KB);
+    double *buf[2] = {s->T, s->T_alt};
+    tb_boot(s, tb_args(s, w), st);
+    const int64_t rows = s->m + 1, cols = s->n + 1;
+    const int64_t nstrips = lpx_cdiv(cols, TB2_COLS);
+    const int64_t rpb = lpx_env_int("LPX_TS_ROWS", 128), nbands = lpx_cdiv(rows, rpb);
+    for (int64_t L = 0; L <= nb; ++L) {
+        TsArgs a{};
+        a.nstrips = nstrips;
+        a.decide = L < nb;
+        a.pass = L >= 1;
+        if (a.decide) {
+            const int64_t k = L;
+            a.s = *s;
+            a.b = (k & 1) ? w.tb2 : w.tb;
+            a.o = (k & 1) ? w.tb : w.tb2;
+            a.uo = k > 0 ? KB : 0;
+            a.u = (int)((k + 1 < nb) ? KB : iters - k * KB);
+            a.dstid = (k + 1 == nb) ? 0 : (int)((k & 1) ^ 1);
+            if (k > 0) a.s.T = buf[(k - 1) & 1]; // the source of the pass beside it
+        }
+        if (a.pass) {
+            const int64_t k = L - 1;
+            const TbWs &h = (k & 1) ? w.tb2 : w.tb;
+            const int srcid = (int)(k & 1), dstid = (k + 1 == nb) ? 0 : (srcid ^ 1);
+            TbFlushArgs &f = a.f;
+            f.T = buf[srcid]; f.Tdst = buf[dstid]; f.rows = rows; f.cols = cols; f.ld = s->ld; f.cond = s->slot_var != nullptr;
+            f.E = h.E; f.R = h.R; f.ldr = h.ldr; f.pslot = h.pslot; f.rowflag = h.rowflag; f.cnt = h.cnt; f.rpb = rpb;
+        }
+        const unsigned grid = a.pass ? (unsigned)(1 + nstrips * nbands) : 1u;
+        lpx_k1_begin(st);
+        lpx_tb_small_launch(a, grid, st);
+        lpx_k1_end(st);
+    }
+    const int64_t npairs = (s->m + 1) * s->ld / 2;
+    hipLaunchKernelGGL(k_tb_syncback, dim3(256), dim3(256), 0, st, (const int64_t *)w.tb.tsel, (const double *)s->T_alt, s->T, npairs);
+    LPX_LAUNCH_CHECK();
+    return LPX_OK;
+}
+
 // ---- column-partitioned tableau with deferred updates: every rank defers the updates of its own slice.  Replicated:
 // x_B (xb[]), the eta columns (formed from the gathered winner's column) and all decisions; local: the slices of the
 // pivot rows (R), of the reduced-cost row (rc[]) and the pricing partials.  Per pivot: propose -> all-gather -> commit;
@@ -1777,6 +1791,16 @@ extern "C" int lpx_tableau_dist_iterate(const lpx_tableau *s, void *comm, int64_
     return tableau_iterate_blocked(s, w, iters, st, (int)block, &d);
 }
 
+extern "C" int lpx_tableau_chain_kind(const lpx_tableau *s)
+{
+    if (s == nullptr || s->m <= 0 || s->n <= 0) return -1;
+    if (s->ratio_rule == LPX_RATIO_HARRIS) return LPX_CHAIN_EAGER;
+    if (t_block_size(s) > 0) return t_use_pipeline(s) ? LPX_CHAIN_PIPELINED : LPX_CHAIN_DEFERRED;
+    if (t_use_small(s)) return LPX_CHAIN_SMALL;
+    if (t_use_fused(s)) return LPX_CHAIN_FUSED;
+    return LPX_CHAIN_EAGER;
+}
+
 extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *stream)
 {
     int rc = check_tableau(s);
@@ -1792,6 +1816,7 @@ extern "C" int lpx_tableau_iterate(const lpx_tableau *s, int64_t iters, void *st
         if (t_use_pipeline(s) && iters > kb) return tableau_iterate_pipelined(s, w, iters, st, kb);
         return tableau_iterate_blocked(s, w, iters, st, kb);
     }
+    if (t_use_small(s)) return tableau_iterate_small(s, w, iters, st);
     if (!harris && t_use_fused(s)) return tableau_iterate_fused(s, w, iters, st);
     const Rank1Plan plan = lpx_rank1_plan(s->m + 1, s->n + 1);
     LPX_REQUIRE(plan.grid.x <= LPX_MAXP, "too many column strips for the partial arrays");

@@ -152,19 +152,16 @@ __device__ __forceinline__ void tb2_walk(const TbFlushArgs &a, int cnt, const d2
     }
 }
 
-// grid (strips of CV * TB2_COLS columns, bands of rpb rows)
-// ONLY = 1: the condensed layout's full blocks alone (every case an fma: the instance whose register count decides the
-// occupancy of the large-tableau loop); ONLY = 2: everything else; 0: both in one kernel
-template <int KB, int NT, int RG, int THREADS = TB2_THREADS, int CV = 1, int ONLY = 0>
-__global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
+// the pass of one workgroup: strip bx of CV * TB2_COLS columns, band by of rpb rows; prs_all = KB * 64 * CV pairs of LDS
+template <int KB, int NT, int RG, int THREADS, int CV, int ONLY>
+__device__ __forceinline__ void tb2_flush_body(const TbFlushArgs &a, int64_t bx, int64_t by, d2_t *prs_all)
 {
-    __shared__ d2_t prs_all[KB * 64 * CV];
     const int cnt = (int)*a.cnt;
     if (cnt <= 0) return;
     if (ONLY == 1 && (cnt != KB || !a.cond)) return;
     if (ONLY == 2 && cnt == KB && a.cond) return;
     const int lane = threadIdx.x & 63;
-    const int64_t col0 = (int64_t)blockIdx.x * (TB2_COLS * CV);
+    const int64_t col0 = bx * (TB2_COLS * CV);
     // every lane stays active (a DPP broadcast from a lane that has left writes nothing): lanes beyond the last column
     // work on column 0's data and store nothing
     int64_t col[CV];
@@ -205,10 +202,20 @@ __global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
     for (int u = 0; u < cnt; ++u)
         if (__ballot((fmany >> u) & 1u) != 0ull) fxmask |= 1u << u;
     __syncthreads();
-    const int64_t row0 = (int64_t)blockIdx.y * a.rpb;
+    const int64_t row0 = by * a.rpb;
     const int64_t row1 = (row0 + a.rpb < a.rows) ? row0 + a.rpb : a.rows;
     const d2_t *prs = prs_all + lane;
     if (ONLY == 1) tb2_walk<KB, NT, RG, true, THREADS, CV, 1>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
     else if (cnt == KB) tb2_walk<KB, NT, RG, true, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
     else tb2_walk<KB, NT, RG, false, THREADS, CV>(a, cnt, prs, fm, fxmask, col, live, row0, row1);
+}
+
+// grid (strips of CV * TB2_COLS columns, bands of rpb rows)
+// ONLY = 1: the condensed layout's full blocks alone (every case an fma: the instance whose register count decides the
+// occupancy of the large-tableau loop); ONLY = 2: everything else; 0: both in one kernel
+template <int KB, int NT, int RG, int THREADS = TB2_THREADS, int CV = 1, int ONLY = 0>
+__global__ __launch_bounds__(THREADS) void k_tb_flush2(TbFlushArgs a)
+{
+    __shared__ d2_t prs_all[KB * 64 * CV];
+    tb2_flush_body<KB, NT, RG, THREADS, CV, ONLY>(a, (int64_t)blockIdx.x, (int64_t)blockIdx.y, prs_all);
 }
