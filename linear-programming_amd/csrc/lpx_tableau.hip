@@ -1668,6 +1668,7 @@ static int tableau_iterate_small(const lpx_tableau *s, const TabWs &w, int64_t i
             a.uo = k > 0 ? KB : 0;
             a.u = (int)((k + 1 < nb) ? KB : iters - k * KB);
             a.dstid = (k + 1 == nb) ? 0 : (int)((k & 1) ^ 1);
+            a.last = k + 1 == nb;
             if (k > 0) a.s.T = buf[(k - 1) & 1]; // the source of the pass beside it
         }
         if (a.pass) {
@@ -1677,6 +1678,8 @@ static int tableau_iterate_small(const lpx_tableau *s, const TabWs &w, int64_t i
             TbFlushArgs &f = a.f;
             f.T = buf[srcid]; f.Tdst = buf[dstid]; f.rows = rows; f.cols = cols; f.ld = s->ld; f.cond = s->slot_var != nullptr;
             f.E = h.E; f.R = h.R; f.ldr = h.ldr; f.pslot = h.pslot; f.rowflag = h.rowflag; f.cnt = h.cnt; f.rpb = rpb;
+            a.fEt = h.Et;
+            a.flde = h.lde;
         }
         const unsigned grid = a.pass ? (unsigned)(1 + nstrips * nbands) : 1u;
         lpx_k1_begin(st);

@@ -88,15 +88,6 @@ __device__ __forceinline__ double ts_max(double x, double y)
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-// workgroup reduction of one double, every thread ends with the result (used once per launch, after the block)
-template <typename Op>
-__device__ __forceinline__ double ts_block(double v, Op op, double *sh)
-{
-    v = ts_wave(v, op);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ts_row16(sh[threadIdx.x & (TS_WAVES - 1)], op);
-}
 struct TsCand { // pricing, Dantzig's rule: the smallest reduced cost, its variable, its slot
     double mn;
     int var, slot;
@@ -112,6 +103,9 @@ struct TsRatio { // a wave's ratio-test winner: ratio, entering-column entry, x_
     double th, dv, xv;
     int row, bv, pos, pad;
 };
+struct TsMinMax { // what the control block reports: the smallest reduced cost priced, the largest entry of the column tested
+    double mn, mx;
+};
 #define TS_NOVAR 0x7fffffff
 __device__ __forceinline__ bool ts_less(double v, int i, double bv, int bi) { return v < bv || (v == bv && i < bi); }
 // a pending pair's pivot row and rewritten slot in one scalar register (both below 1024)
@@ -119,6 +113,69 @@ __device__ __forceinline__ int ts_pack(int row, int slot) { return (row << 16) |
 #define TS_ROW(pk) ((pk) >> 16)
 #define TS_SLOT(pk) ((pk) & 0xffff)
 #define TS_NOPAIR ts_pack(0x7000, 0x7000)
+
+// The two update chains of a pivot.  `pkv`: lane u of every wave holds pending pair u (0 .. KB-1: the old block's, KB ..
+// 2 KB - 1: this block's); `wrow` / `wslot`: the pairs whose pivot row / rewritten slot belongs to a thread of THIS wave.
+// Almost every pivot enters a column no pending pair has rewritten and leaves by a row no pending pair pivoted on: then
+// (GENERAL == false) a step is one fma, plus a select in the one wave the pair's row / slot lives in.
+// (`nsteps` is a constant wherever this is inlined: the pivot loop is unrolled)
+template <int KB, int BASE, bool GENERAL>
+__device__ __forceinline__ double ts_col_steps(int nsteps, double di, const double (&e)[KB], const double (&rk)[KB], int pkv,
+                                               unsigned wrow, int slot, int t, int wave, bool cond)
+{
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        if (u >= nsteps) break;
+        if (GENERAL) {
+            const int pk = __builtin_amdgcn_readlane(pkv, BASE + u), pu = TS_ROW(pk);
+            if (slot == TS_SLOT(pk)) {
+                di = cond ? e[u] : ((t == pu) ? 1.0 : 0.0);
+            } else {
+                double acc = di;
+                if ((pu >> 6) == wave) {
+                    TS_KEEP_BRANCH();
+                    acc = (t == pu) ? -0.0 : di;
+                }
+                di = fma(e[u], rk[u], acc);
+            }
+        } else {
+            double acc = di;
+            if (__builtin_expect((wrow >> (BASE + u)) & 1u, 0)) {
+                TS_KEEP_BRANCH();
+                acc = (t == TS_ROW(__builtin_amdgcn_readlane(pkv, BASE + u))) ? -0.0 : di;
+            }
+            di = fma(e[u], rk[u], acc);
+        }
+    }
+    return di;
+}
+template <int KB, int BASE, bool GENERAL>
+__device__ __forceinline__ double ts_row_steps(int nsteps, double rowp, const double (&er)[KB], const double (&rr)[KB], int pkv,
+                                               unsigned wslot, int r, int t, int wave, bool cond)
+{
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        if (u >= nsteps) break;
+        if (GENERAL) {
+            const int pk = __builtin_amdgcn_readlane(pkv, BASE + u), su = TS_SLOT(pk);
+            const bool isr = r == TS_ROW(pk);
+            double acc = rowp;
+            if (isr) acc = -0.0;
+            rowp = fma(er[u], rr[u], acc);
+            if ((su >> 6) == wave) {
+                TS_KEEP_BRANCH();
+                if (t == su) rowp = cond ? er[u] : (isr ? 1.0 : 0.0);
+            }
+        } else {
+            rowp = fma(er[u], rr[u], rowp);
+            if (__builtin_expect((wslot >> (BASE + u)) & 1u, 0)) {
+                TS_KEEP_BRANCH();
+                if (t == TS_SLOT(__builtin_amdgcn_readlane(pkv, BASE + u))) rowp = cond ? er[u] : 0.0;
+            }
+        }
+    }
+    return rowp;
+}
 
 // PO: pairs of the block whose pass runs beside this workgroup -- none (the first block of a call) or a whole block (a block
 // that ends early ends the loop), so the old block's chain is compiled for its length
@@ -132,7 +189,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
     __shared__ __align__(16) double sh_rk[2 * KB]; // R_u[slot]: the entering column's entries of the pending pivot rows (old block, then new)
     __shared__ __align__(16) double sh_er[2 * KB]; // e_u[r]: the leaving row's multipliers of the pending updates
     __shared__ double sh_em[2];                    // the reduced-cost row's multiplier of this pivot (row m's eta entry)
-    __shared__ double sh_red[2][TS_WAVES];         // the two closing reductions
+    __shared__ __align__(16) TsMinMax sh_red[TS_WAVES]; // the closing reduction
     __shared__ int sh_piv[KB][4];                  // (row, slot, entering, leaving) of the block's pivots, for the closing bookkeeping
     __shared__ __align__(16) TsArgs sh_args;       // the launch record, for the closing stores
 #ifdef LPX_TS_STAMPS
@@ -151,22 +208,14 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
     const int32_t status0 = s.ctrl->status;
     const bool f32 = s.ctrl->f32_phase != 0;
     double eo[KB], en[KB], ro[KB], rn[KB];
-    int pk_o[KB], pk_n[KB];
+    int pkv = (PO > 0 && lane < PO) ? ts_pack((int)a.o.prow[lane], (int)a.o.pslot[lane]) : TS_NOPAIR;
     {
-        const int pv = (PO > 0 && lane < PO) ? ts_pack((int)a.o.prow[lane], (int)a.o.pslot[lane]) : TS_NOPAIR;
-#pragma unroll
-        for (int u = 0; u < KB; u += 2) {
-            const d2_t e2 = (u < PO && inrow) ? *(const d2_t *)(a.o.E + (int64_t)t * TB_KMAX + u) : d2_t{0.0, 0.0};
-            eo[u] = e2[0];
-            eo[u + 1] = e2[1];
-        }
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
+            eo[u] = (u < PO && inrow) ? a.o.Et[u * a.o.lde + t] : 0.0; // the pairs cross launches transposed: a row of 8 KB a pair
             ro[u] = (u < PO && incol) ? a.o.R[u * a.o.ldr + t] : 0.0;
             en[u] = 0.0;
             rn[u] = 0.0;
-            pk_o[u] = __builtin_amdgcn_readlane(pv, u);
-            pk_n[u] = TS_NOPAIR;
         }
     }
     double rc = inrc ? a.b.rc[t] : LPX_INF, xb = inx ? a.b.xb[t] : 0.0;
@@ -177,6 +226,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
     if (inrow) a.b.rowflag[t] = 0u;
     if (t == 0) *a.b.cnt = 0;
     if (status0 != LPX_RUNNING) return;
+    unsigned wrow = (unsigned)__ballot((TS_ROW(pkv) >> 6) == wave), wslot = (unsigned)__ballot((TS_SLOT(pkv) >> 6) == wave);
     int status = LPX_RUNNING;
     int last_j = -1;
     double last_ratio = 0.0;
@@ -253,42 +303,21 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TS_STAMP(1);
-        if (PO > 0) {
-            double rk[KB];
+        {
+            const bool general = __ballot(TS_SLOT(pkv) == slot) != 0ull; // the entering column is one a pending update rewrote
+            if (PO > 0) {
+                double rk[KB];
 #pragma unroll
-            for (int u = 0; u < KB; ++u) rk[u] = sh_rk[u];
-#pragma unroll
-            for (int u = 0; u < PO; ++u) {
-                const int pu = TS_ROW(pk_o[u]);
-                if (slot == TS_SLOT(pk_o[u])) {
-                    di = cond ? eo[u] : ((t == pu) ? 1.0 : 0.0);
-                } else {
-                    double acc = di;
-                    if ((pu >> 6) == wave) {
-                        TS_KEEP_BRANCH();
-                        acc = (t == pu) ? -0.0 : di;
-                    }
-                    di = fma(eo[u], rk[u], acc);
-                }
+                for (int u = 0; u < KB; ++u) rk[u] = sh_rk[u];
+                if (general) di = ts_col_steps<KB, 0, true>(PO, di, eo, rk, pkv, wrow, slot, t, wave, cond);
+                else di = ts_col_steps<KB, 0, false>(PO, di, eo, rk, pkv, wrow, slot, t, wave, cond);
             }
-        }
-        if (P > 0) {
-            double rk[KB];
+            if (P > 0) {
+                double rk[KB];
 #pragma unroll
-            for (int u = 0; u < P; ++u) rk[u] = sh_rk[KB + u];
-#pragma unroll
-            for (int u = 0; u < P; ++u) {
-                const int pu = TS_ROW(pk_n[u]);
-                if (slot == TS_SLOT(pk_n[u])) {
-                    di = cond ? en[u] : ((t == pu) ? 1.0 : 0.0);
-                } else {
-                    double acc = di;
-                    if ((pu >> 6) == wave) {
-                        TS_KEEP_BRANCH();
-                        acc = (t == pu) ? -0.0 : di;
-                    }
-                    di = fma(en[u], rk[u], acc);
-                }
+                for (int u = 0; u < KB; ++u) rk[u] = (u < P) ? sh_rk[KB + u] : 0.0;
+                if (general) di = ts_col_steps<KB, KB, true>(P, di, en, rk, pkv, wrow, slot, t, wave, cond);
+                else di = ts_col_steps<KB, KB, false>(P, di, en, rk, pkv, wrow, slot, t, wave, cond);
             }
         }
         TS_STAMP(2);
@@ -347,38 +376,21 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
 #endif
         TS_STAMP(4);
         // ---- row r as the pending updates leave it (tb_row_chain's expressions): this update's old pivot row
-        if (PO > 0) {
-            double er[KB];
+        {
+            const bool general = __ballot(TS_ROW(pkv) == r) != 0ull; // the leaving row is one a pending update pivoted on
+            if (PO > 0) {
+                double er[KB];
 #pragma unroll
-            for (int u = 0; u < KB; ++u) er[u] = sh_er[u];
-#pragma unroll
-            for (int u = 0; u < PO; ++u) {
-                const int su = TS_SLOT(pk_o[u]);
-                const bool isr = r == TS_ROW(pk_o[u]);
-                double acc = rowp;
-                if (isr) acc = -0.0;
-                rowp = fma(er[u], ro[u], acc);
-                if ((su >> 6) == wave) {
-                    TS_KEEP_BRANCH();
-                    if (t == su) rowp = cond ? er[u] : (isr ? 1.0 : 0.0);
-                }
+                for (int u = 0; u < KB; ++u) er[u] = sh_er[u];
+                if (general) rowp = ts_row_steps<KB, 0, true>(PO, rowp, er, ro, pkv, wslot, r, t, wave, cond);
+                else rowp = ts_row_steps<KB, 0, false>(PO, rowp, er, ro, pkv, wslot, r, t, wave, cond);
             }
-        }
-        if (P > 0) {
-            double er[KB];
+            if (P > 0) {
+                double er[KB];
 #pragma unroll
-            for (int u = 0; u < P; ++u) er[u] = sh_er[KB + u];
-#pragma unroll
-            for (int u = 0; u < P; ++u) {
-                const int su = TS_SLOT(pk_n[u]);
-                const bool isr = r == TS_ROW(pk_n[u]);
-                double acc = rowp;
-                if (isr) acc = -0.0;
-                rowp = fma(er[u], rn[u], acc);
-                if ((su >> 6) == wave) {
-                    TS_KEEP_BRANCH();
-                    if (t == su) rowp = cond ? er[u] : (isr ? 1.0 : 0.0);
-                }
+                for (int u = 0; u < KB; ++u) er[u] = (u < P) ? sh_er[KB + u] : 0.0;
+                if (general) rowp = ts_row_steps<KB, KB, true>(P, rowp, er, rn, pkv, wslot, r, t, wave, cond);
+                else rowp = ts_row_steps<KB, KB, false>(P, rowp, er, rn, pkv, wslot, r, t, wave, cond);
             }
         }
         TS_STAMP(5);
@@ -398,7 +410,9 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         // this pivot joins the pending ones
         en[P] = eg;
         rn[P] = rowp;
-        pk_n[P] = ts_pack(r, slot);
+        if (lane == KB + P) pkv = ts_pack(r, slot);
+        wrow |= (unsigned)((r >> 6) == wave) << (KB + P);
+        wslot |= (unsigned)((slot >> 6) == wave) << (KB + P);
         if (t == 0) {
             sh_piv[P][0] = r;
             sh_piv[P][1] = slot;
@@ -413,15 +427,24 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         // pricing barrier, sh_er after its ratio barrier, and the records alternate two copies
     }
     // ---- what the control block reports of the last pricing and the last ratio test: the smallest reduced cost, the
-    // entering column's maximum (exact whatever the order: the values the per-pivot kernels leave there)
-    const double last_price = ts_block(rc_priced, [](double x, double y) { return ts_min(x, y); }, sh_red[0]);
-    const double last_dmax = ts_block(d_tested, [](double x, double y) { return ts_max(x, y); }, sh_red[1]);
-    // ---- the block's pairs and the state the next launch (or the caller) starts from
+    // entering column's maximum (exact whatever the order: the values the per-pivot kernels leave there).  Only a launch
+    // whose control block the caller can see pays for them: the last of a call, or the one that ends the loop
     const TsArgs &z = sh_args;
+    const bool report = z.last != 0 || status != LPX_RUNNING;
+    TsMinMax mm{rc_priced, d_tested};
+    if (report) {
+        mm = ts_wave(mm, [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
+        if (lane == 0) sh_red[wave] = mm;
+        __syncthreads();
+        mm = ts_row16(sh_red[lane & (TS_WAVES - 1)], [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
+    }
+    // ---- the block's pairs and the state the next launch (or the caller) starts from
     if (inrow) {
-        double *dst = z.b.E + (int64_t)t * TB_KMAX;
+        double *dst = z.b.Et + t;
+        const int64_t lde = z.b.lde;
 #pragma unroll
-        for (int u = 0; u < KB; u += 2) *(d2_t *)(dst + u) = d2_t{en[u], en[u + 1]}; // zeros beyond `done`
+        for (int u = 0; u < KB; ++u)
+            if (u < done) dst[u * lde] = en[u];
     }
     if (incol) {
         double *dst = z.b.R + t;
@@ -438,39 +461,52 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
     }
     if (mycol) z.s.slot_var[t] = var;
     if (t == 0) {
+        // one thread, in pivot order (a variable may leave and enter again inside a block); everything it needs is read
+        // first, so that the stores follow one another instead of each waiting for its own LDS reads
         lpx_ctrl *ctrl = z.s.ctrl;
-        const int64_t pivots0 = ctrl->pivots;
-        for (int P = 0; P < done; ++P) { // in pivot order: a variable may leave and enter again inside a block
-            const int r = sh_piv[P][0], slot = sh_piv[P][1], j = sh_piv[P][2], leaving = sh_piv[P][3];
-            if (cond) {
-                z.s.var_slot[leaving] = slot;
-                z.s.var_slot[j] = -1;
-            } else {
-                t_swap_columns(z.s, j, leaving);
+        int64_t *var_slot = z.s.var_slot, *log = z.s.log, *prow = z.b.prow, *pslot = z.b.pslot;
+        const int64_t log_cap = z.s.log_cap, pivots0 = ctrl->pivots;
+        int pr[KB], ps[KB], pj[KB], pl[KB];
+#pragma unroll
+        for (int P = 0; P < KB; ++P) {
+            pr[P] = sh_piv[P][0];
+            ps[P] = sh_piv[P][1];
+            pj[P] = sh_piv[P][2];
+            pl[P] = sh_piv[P][3];
+        }
+#pragma unroll
+        for (int P = 0; P < KB; ++P) {
+            if (P < done) {
+                if (cond) {
+                    var_slot[pl[P]] = ps[P];
+                    var_slot[pj[P]] = -1;
+                } else {
+                    t_swap_columns(z.s, pj[P], pl[P]);
+                }
+                const int64_t k = pivots0 + P;
+                if (log && k < log_cap) {
+                    log[3 * k + 0] = pr[P];
+                    log[3 * k + 1] = pj[P];
+                    log[3 * k + 2] = pl[P];
+                }
+                prow[P] = pr[P];
+                pslot[P] = ps[P];
             }
-            const int64_t k = pivots0 + P;
-            if (z.s.log && k < z.s.log_cap) {
-                z.s.log[3 * k + 0] = r;
-                z.s.log[3 * k + 1] = j;
-                z.s.log[3 * k + 2] = leaving;
-            }
-            z.b.prow[P] = r;
-            z.b.pslot[P] = slot;
         }
         *z.b.cnt = done;
         if (done > 0) z.b.tsel[0] = z.dstid;
         ctrl->counter += priced;
         ctrl->pivots = pivots0 + done;
-        ctrl->price_val = last_price;
+        if (report) ctrl->price_val = mm.mn;
         if (status != LPX_RUNNING) ctrl->status = status;
         if (last_j >= 0) ctrl->enter_j = last_j;
-        if (status == LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = last_dmax;
+        if (status == LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = mm.mx;
         if (done > 0) {
             ctrl->enter_slot = sh_piv[done - 1][1];
             ctrl->leave_r = sh_piv[done - 1][0];
             ctrl->leave_var = sh_piv[done - 1][3];
             ctrl->ratio_val = last_ratio;
-            if (status != LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = last_dmax;
+            if (report && status != LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = mm.mx;
             ctrl->flip = 0;
             ctrl->f32_phase = 0;
         }
@@ -495,7 +531,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
 // decision role)
 #define TS_RP 2
 template <int KB>
-__device__ __forceinline__ void ts_pass(const TbFlushArgs &a, int64_t bx, int64_t by, d2_t *prs)
+__device__ __forceinline__ void ts_pass(const TbFlushArgs &a, const double *Et, int64_t lde, int64_t bx, int64_t by, d2_t *prs)
 {
     const int cnt = (int)*a.cnt;
     if (cnt <= 0) return;
@@ -527,7 +563,7 @@ __device__ __forceinline__ void ts_pass(const TbFlushArgs &a, int64_t bx, int64_
             x[q] = *(const d2_t *)(a.T + i * a.ld + col);
             rf[q] = a.rowflag[i];
 #pragma unroll
-            for (int u = 0; u < KB; ++u) e[q][u] = a.E[i * TB_KMAX + u];
+            for (int u = 0; u < KB; ++u) e[q][u] = Et[u * lde + i];
         }
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
@@ -559,7 +595,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tb_small(TsArgs a)
     __shared__ d2_t prs_all[KB * 64];
     const int64_t w = (int64_t)blockIdx.x - 1;
     const int64_t by = w / a.nstrips, bx = w - by * a.nstrips;
-    ts_pass<KB>(a.f, bx, by, prs_all);
+    ts_pass<KB>(a.f, a.fEt, a.flde, bx, by, prs_all);
 }
 
 void lpx_tb_small_launch(const TsArgs &a, unsigned grid, void *stream)
