@@ -95,10 +95,6 @@ struct TsCand { // pricing, Dantzig's rule: the smallest reduced cost, its varia
 struct TsBland { // pricing, Bland's rule: the smallest variable id of negative reduced cost, its slot; any cost below -atol
     int var, slot, live, pad;
 };
-struct TsKey { // first minimum ratio: (th, row) lexicographic; rows are distinct
-    double th;
-    int row, pos; // pos: some entry of the column is positive (the loop goes on)
-};
 struct TsRatio { // a wave's ratio-test winner: ratio, entering-column entry, x_B, row, basic variable
     double th, dv, xv;
     int row, bv, pos, pad;
@@ -255,10 +251,16 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
             c = ts_wave(c, [](TsCand x, TsCand y) { return ts_less(y.mn, y.var, x.mn, x.var) ? y : x; });
             if (lane == 0) sh_price[ph][wave] = c;
             __syncthreads();
-            c = ts_row16(sh_price[ph][lane & (TS_WAVES - 1)], [](TsCand x, TsCand y) { return ts_less(y.mn, y.var, x.mn, x.var) ? y : x; });
-            optimal = lpx_is_optimal_min(c.mn);
-            slot = c.slot;
-            j = c.var;
+            // the sixteen partials: smallest cost, smallest id among the waves that have it, and that wave's slot
+            const TsCand *wc = &sh_price[ph][lane & (TS_WAVES - 1)];
+            const double wmn = wc->mn;
+            const int wvar = wc->var;
+            const double mn = ts_row16(wmn, [](double x, double y) { return ts_min(x, y); });
+            const int minvar = ts_row16(wmn == mn ? wvar : TS_NOVAR, [](int x, int y) { return y < x ? y : x; });
+            const unsigned who = (unsigned)__ballot(wmn == mn && wvar == minvar) & 0xffffu;
+            optimal = lpx_is_optimal_min(mn);
+            slot = sh_price[ph][who ? __ffs(who) - 1 : 0].slot;
+            j = minvar;
         } else {
             // the loop ends when min rc >= -atol (lpx_is_optimal_min), i.e. when no reduced cost lies below -atol
             const int myvar = (inrc && rc < 0.0) ? var : TS_NOVAR; // first negative index: smallest variable id (ids are distinct)
@@ -269,14 +271,14 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
             c.pad = 0;
             if (lane == 0) sh_bland[ph][wave] = c;
             __syncthreads();
-            c = ts_row16(sh_bland[ph][lane & (TS_WAVES - 1)], [](TsBland x, TsBland y) {
-                TsBland z = (y.var < x.var) ? y : x;
-                z.live = x.live | y.live;
-                return z;
-            });
-            optimal = c.live == 0;
-            slot = c.slot;
-            j = c.var;
+            // the sixteen partials: smallest id, the wave that has it (ids are distinct), its slot
+            const TsBland *wb = &sh_bland[ph][lane & (TS_WAVES - 1)];
+            const int wvar = wb->var;
+            const int minvar = ts_row16(wvar, [](int x, int y) { return y < x ? y : x; });
+            const unsigned who = (unsigned)__ballot(wvar == minvar) & 0xffffu;
+            optimal = ((unsigned)__ballot(wb->live != 0) & 0xffffu) == 0u;
+            slot = sh_bland[ph][who ? __ffs(who) - 1 : 0].slot;
+            j = minvar;
         }
         TS_STAMP(0);
         priced = P + 1;
@@ -333,26 +335,21 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
                            __builtin_amdgcn_readlane(bas, src), __ballot(inx && di > 0.0) != 0ull, 0};
         if (lane == 0) sh_ratio[ph][wave] = wrec;
         __syncthreads();
+        // the sixteen partials: the smallest ratio, the FIRST wave that has it (rows ascend with the wave), its record
         const TsRatio *wr = &sh_ratio[ph][lane & (TS_WAVES - 1)];
-        const TsKey key = ts_row16(TsKey{wr->th, wr->row, wr->pos}, [](TsKey x, TsKey y) {
-            TsKey z = ts_less(y.th, y.row, x.th, x.row) ? y : x;
-            z.pos = x.pos | y.pos;
-            return z;
-        });
+        const double wth = wr->th;
+        const double thmin = ts_row16(wth, [](double x, double y) { return ts_min(x, y); });
+        const unsigned who = (unsigned)__ballot(wth == thmin) & 0xffffu;
+        const bool anypos = ((unsigned)__ballot(wr->pos != 0) & 0xffffu) != 0u;
         TS_STAMP(3);
-        if (__builtin_amdgcn_readfirstlane(key.pos) == 0) {
+        if (!anypos) {
             status = LPX_PRIMAL_UNBOUNDED;
             last_j = j;
             break;
         }
-        const int r = __builtin_amdgcn_readfirstlane(key.row);
-        if (r < 0 || r >= m) { // as above
-            status = TS_INTERNAL;
-            break;
-        }
-        const TsRatio win = sh_ratio[ph][r >> 6];
-        const int leaving = __builtin_amdgcn_readfirstlane(win.bv);
-        if (leaving < 0 || leaving >= n_global) {
+        const TsRatio win = sh_ratio[ph][who ? __ffs(who) - 1 : 0];
+        const int r = __builtin_amdgcn_readfirstlane(win.row), leaving = __builtin_amdgcn_readfirstlane(win.bv);
+        if (r < 0 || r >= m || leaving < 0 || leaving >= n_global) { // as above
             status = TS_INTERNAL;
             break;
         }
@@ -421,7 +418,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         }
         done = P + 1;
         last_j = j;
-        last_ratio = key.th;
+        last_ratio = thmin;
         TS_STAMP(6);
         // no barrier closes a pivot: the next one's first LDS write that anybody here still reads (sh_rk) comes after its
         // pricing barrier, sh_er after its ratio barrier, and the records alternate two copies
