@@ -38,21 +38,19 @@ struct Rank1Args {
     int fold;
 };
 
-// NT: 0 plain; 1 non-temporal loads and stores; 2 / 3 non-temporal loads / stores only; 5 non-temporal loads and
-// WRITE-THROUGH (sc1) stores: the line leaves the XCD's L2 at once instead of sitting there dirty, so the L2 write-back
-// at the end of every kernel that runs BESIDE this stream (the decision kernels of the pipelined chain) finds nothing
-// of ours to flush (MI355X_MICROARCH.md, stores of each flavour; buffer_wbl2: 1.7 us clean, 6.5 us with dirty lines)
+// NT: 0 plain; 1 non-temporal loads and stores; 2 / 3 non-temporal loads / stores only.  (Write-through `sc1` stores
+// for the pass of the pipelined chain, so that kernels ending beside it find no dirty lines of its to write back, were
+// measured in round 3 and lost: 21.5 k against 22.6 k pivots/s)
 template <int NT>
 __device__ __forceinline__ d2_t lpx_ld2(const double *p)
 {
-    if (NT == 1 || NT == 2 || NT == 5) return __builtin_nontemporal_load((const d2_t *)p);
+    if (NT == 1 || NT == 2) return __builtin_nontemporal_load((const d2_t *)p);
     return *(const d2_t *)p;
 }
 template <int NT>
 __device__ __forceinline__ void lpx_st2(double *p, d2_t v)
 {
-    if (NT == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-    else if (NT == 1 || NT == 3) __builtin_nontemporal_store(v, (d2_t *)p);
+    if (NT == 1 || NT == 3) __builtin_nontemporal_store(v, (d2_t *)p);
     else *(d2_t *)p = v;
 }
 

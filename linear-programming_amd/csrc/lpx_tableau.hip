@@ -1668,7 +1668,6 @@ static int tableau_iterate_small(const lpx_tableau *s, const TabWs &w, int64_t i
             a.uo = k > 0 ? KB : 0;
             a.u = (int)((k + 1 < nb) ? KB : iters - k * KB);
             a.dstid = (k + 1 == nb) ? 0 : (int)((k & 1) ^ 1);
-            a.last = k + 1 == nb;
             if (k > 0) a.s.T = buf[(k - 1) & 1]; // the source of the pass beside it
         }
         if (a.pass) {

@@ -424,17 +424,14 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         // pricing barrier, sh_er after its ratio barrier, and the records alternate two copies
     }
     // ---- what the control block reports of the last pricing and the last ratio test: the smallest reduced cost, the
-    // entering column's maximum (exact whatever the order: the values the per-pivot kernels leave there).  Only a launch
-    // whose control block the caller can see pays for them: the last of a call, or the one that ends the loop
+    // entering column's maximum (exact whatever the order: the values the per-pivot kernels leave there).  Every launch
+    // leaves them: the loop may end on the first pricing of the next one, which then has no ratio test of its own to report
     const TsArgs &z = sh_args;
-    const bool report = z.last != 0 || status != LPX_RUNNING;
     TsMinMax mm{rc_priced, d_tested};
-    if (report) {
-        mm = ts_wave(mm, [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
-        if (lane == 0) sh_red[wave] = mm;
-        __syncthreads();
-        mm = ts_row16(sh_red[lane & (TS_WAVES - 1)], [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
-    }
+    mm = ts_wave(mm, [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
+    if (lane == 0) sh_red[wave] = mm;
+    __syncthreads();
+    mm = ts_row16(sh_red[lane & (TS_WAVES - 1)], [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
     // ---- the block's pairs and the state the next launch (or the caller) starts from
     if (inrow) {
         double *dst = z.b.Et + t;
@@ -494,7 +491,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         if (done > 0) z.b.tsel[0] = z.dstid;
         ctrl->counter += priced;
         ctrl->pivots = pivots0 + done;
-        if (report) ctrl->price_val = mm.mn;
+        ctrl->price_val = mm.mn;
         if (status != LPX_RUNNING) ctrl->status = status;
         if (last_j >= 0) ctrl->enter_j = last_j;
         if (status == LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = mm.mx;
@@ -503,7 +500,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
             ctrl->leave_r = sh_piv[done - 1][0];
             ctrl->leave_var = sh_piv[done - 1][3];
             ctrl->ratio_val = last_ratio;
-            if (report && status != LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = mm.mx;
+            if (status != LPX_PRIMAL_UNBOUNDED) ctrl->aux_val = mm.mx;
             ctrl->flip = 0;
             ctrl->f32_phase = 0;
         }

@@ -12,7 +12,6 @@ struct TsArgs {
     lpx_tableau s;
     TbWs b, o;
     int u, uo, dstid;
-    int last;      // the call's last deciding launch: it leaves the control block's reported values (price_val, aux_val)
     TbFlushArgs f; // the pass of the previous block (f.cnt: its pair count; no pass when decide-only)
     const double *fEt; // its eta columns, transposed (TbWs::Et: this chain moves them as rows; f.E is not used)
     int64_t flde;

@@ -3,21 +3,10 @@
 
 void lpx_tb_flush_launch32(const TbFlushArgs &f, int nt, dim3 grid, hipStream_t st)
 {
-    const int dyn = lpx_env_int("LPX_TB_DYNLDS", 0); // experiment: extra LDS per workgroup = fewer resident workgroups per CU
-    if (nt && lpx_env_int("LPX_TB_RG", 8) == 4) {
-        hipLaunchKernelGGL((k_tb_flush2<32, 1, 4, TB2_THREADS, 1, 1>), grid, dim3(TB2_THREADS), dyn, st, f);
-        hipLaunchKernelGGL((k_tb_flush2<32, 1, 8, TB2_THREADS, 1, 2>), grid, dim3(TB2_THREADS), 0, st, f);
-        return;
-    }
-    if (nt && lpx_env_int("LPX_TB_WT", 1)) { // write-through stores in the hot instance (lpx_rank1.hpp, NT = 5)
-        hipLaunchKernelGGL((k_tb_flush2<32, 5, 8, TB2_THREADS, 1, 1>), grid, dim3(TB2_THREADS), dyn, st, f);
-        hipLaunchKernelGGL((k_tb_flush2<32, 1, 8, TB2_THREADS, 1, 2>), grid, dim3(TB2_THREADS), 0, st, f);
-        return;
-    }
     if (nt) {
         // two kernels, each leaves at once when the block is the other's: the condensed layout's full blocks in an instance
         // of their own (123 VGPRs, 4 waves per SIMD; with the general chains in the same kernel: 218 and 2), the rest
-        hipLaunchKernelGGL((k_tb_flush2<32, 1, 8, TB2_THREADS, 1, 1>), grid, dim3(TB2_THREADS), dyn, st, f);
+        hipLaunchKernelGGL((k_tb_flush2<32, 1, 8, TB2_THREADS, 1, 1>), grid, dim3(TB2_THREADS), 0, st, f);
         hipLaunchKernelGGL((k_tb_flush2<32, 1, 8, TB2_THREADS, 1, 2>), grid, dim3(TB2_THREADS), 0, st, f);
     }
     else hipLaunchKernelGGL((k_tb_flush2<32, 0, 8>), grid, dim3(TB2_THREADS), 0, st, f);

@@ -245,6 +245,7 @@ def test_graph_capture_failure_unwinds_and_the_next_call_works(env, monkeypatch)
     st = env["torch"].cuda.current_stream().cuda_stream
     lib.check(L.lpx_ctrl_begin_solve(eng.s.ctrl, st))
     monkeypatch.setenv("LPX_GRAPH_UNROLL", "6")  # a key of its own: nothing cached from other tests
+    monkeypatch.setenv("LPX_TABLEAU_SMALL_CHAIN", "0")  # the graph-captured chain (one launch per pivot), not one launch per 8 pivots
     monkeypatch.setenv("LPX_GRAPH_TEST_FAIL", "arg")
     assert L.lpx_tableau_iterate(C.byref(eng.s), 12, st) == -1  # LPX_E_ARG out of the captured chain
     assert b"captured chain" in L.lpx_last_error()

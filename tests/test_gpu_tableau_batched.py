@@ -14,17 +14,24 @@ def logged(cls, cap):
     return type(cls.__name__ + "Logged", (cls,), {"_LOG_CAP": cap})
 
 
-@pytest.mark.parametrize("chain", ["one-launch", "three-launch"])
+def pick_chain(chain, monkeypatch):
+    """small: one launch per 8 pivots (the default where a workgroup holds a row and a column per thread); one-launch: one
+    launch per pivot on two alternating buffers; three-launch: the in-place three-kernel chain of the large configurations"""
+    if chain != "small":
+        monkeypatch.setenv("LPX_TABLEAU_SMALL_CHAIN", "0")
+    if chain == "three-launch":
+        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+
+
+@pytest.mark.parametrize("chain", ["small", "one-launch", "three-launch"])
 @pytest.mark.parametrize("condensed", [True, False], ids=["condensed", "full"])
 @pytest.mark.parametrize("cs", PRIMAL, ids=case_id)
 def test_tableau_matches_reference(cs, condensed, chain, monkeypatch):
-    """Both layouts of the carried tableau -- nonbasic columns only (the default) and every column -- and both launch
-    chains -- one launch per pivot on two alternating buffers (default at these sizes) and the in-place three-kernel
-    chain of the large configurations -- against the reference's golden pivot sequences and results."""
+    """Both layouts of the carried tableau -- nonbasic columns only (the default) and every column -- and the three launch
+    chains of tableaus this size against the reference's golden pivot sequences and results."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
 
-    if chain == "three-launch":
-        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+    pick_chain(chain, monkeypatch)
     ref = cs["ref"]
     c, A, b, basis = problem_of(cs)
     s = logged(PrimalTableauSimplexSolver, max(16, len(ref["pivots"]) + 1))(c, A, b, basis, condensed=condensed)
@@ -36,14 +43,13 @@ def test_tableau_matches_reference(cs, condensed, chain, monkeypatch):
     assert_close(res.cost, ref["cost"], "cost")
 
 
-@pytest.mark.parametrize("chain", ["one-launch", "three-launch"])
+@pytest.mark.parametrize("chain", ["small", "one-launch", "three-launch"])
 def test_tableau_bit_exact_vs_oracle(chain, monkeypatch):
     """Elementwise path (no reductions over floating-point sums): the carried tableau must be bit-identical."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
     from oracle import oracle as O
 
-    if chain == "three-launch":
-        monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+    pick_chain(chain, monkeypatch)
     c, A, b, basis = gen.gen_primal(96, 200, 11)
     s = PrimalTableauSimplexSolver(c, A, b, basis, condensed=False)
     sc = PrimalTableauSimplexSolver(c, A, b, basis, condensed=True)
@@ -75,13 +81,17 @@ def test_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, monke
     """The single-launch chain with several lookahead workgroups (m + 1 > 256), several column strips and every update
     tile height, in calls of odd and even length (ping-pong parity, hipGraph replays from 32 iterations on): pivot log,
     tableau, basis and column maps bit-identical to the oracle's loop on the same layout."""
+    import ctypes as C
+
+    from linprog_amd import _lib
     from linprog_amd.tableau import PrimalTableauSimplexSolver
     from oracle import oracle as O
 
     monkeypatch.setenv("LPX_FUSED_ROWS", rows)
+    monkeypatch.setenv("LPX_TABLEAU_SMALL_CHAIN", "0")
     c, A, b, basis = gen.gen_primal(m, n, 5)
     s = logged(PrimalTableauSimplexSolver, 512)(c, A, b, basis, condensed=condensed)
-    assert s._engine.T_alt is not None
+    assert s._engine.T_alt is not None and int(_lib.load().lpx_tableau_chain_kind(C.byref(s._engine.s))) == _lib.CHAIN_FUSED
     o = O.OracleTableau(c, A, b, basis, condensed=condensed, log_cap=512)
     done = 0
     for k in (1, 2, 5, 64, 33):
@@ -98,12 +108,13 @@ def test_one_launch_chain_bit_exact_multi_workgroup(m, n, condensed, rows, monke
             assert np.array_equal(s._engine.slot_var.cpu().numpy(), o.slot_var)
 
 
-def test_one_launch_chain_runs_to_the_reference_optimum_and_stays_there():
+def test_one_launch_chain_runs_to_the_reference_optimum_and_stays_there(monkeypatch):
     """Full solve through the single-launch chain (graph replays, termination inside a replayed chunk), then a second
     solve() on the optimal state: iters == 1, nothing moves (tests/test_primal_base_solvers.py:24-34's re-entrancy)."""
     from linprog_amd.tableau import PrimalTableauSimplexSolver
     from oracle import oracle as O
 
+    monkeypatch.setenv("LPX_TABLEAU_SMALL_CHAIN", "0")
     c, A, b, basis = gen.gen_primal(128, 256, 0)
     s = logged(PrimalTableauSimplexSolver, 1024)(c, A, b, basis)
     res = s.solve(100000)
