@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
                 status = LPX_OPTIMAL;
                 break;
             }
-            jv = wave_imin(neg ? var : LPX_NOIDX); // first negative index, by variable id (:135-138)
+            // first negative index, by variable id (:135-138); ids are below 2^31 (n <= 256 here): a 32-bit reduction
+            jv = (int64_t)wave_imin32(neg ? (int)var : 0x7FFFFFFF);
             jl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(var == jv)) - 1);
         } else {
             const bool negx = row && xb < 0.0;

@@ -76,13 +76,15 @@ struct LpxWords {
     static_assert(sizeof(T) % 4 == 0, "whole dwords");
     int w[sizeof(T) / 4];
 };
+// (every destination lane of these controls has a source and the masks are full, so the move's "old" operand is dead:
+// naming none saves the copy, and its wait states, that tying it to the source costs -- two VALU instructions a dword)
 template <typename T, int CTRL>
 __device__ __forceinline__ T lpx_dpp_move(T v)
 {
     LpxWords<T> u;
     __builtin_memcpy(&u, &v, sizeof(T));
 #pragma unroll
-    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = __builtin_amdgcn_update_dpp(u.w[k], u.w[k], CTRL, 0xf, 0xf, false);
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = __builtin_amdgcn_mov_dpp(u.w[k], CTRL, 0xf, 0xf, false);
     T r;
     __builtin_memcpy(&r, &u, sizeof(T));
     return r;
@@ -157,13 +159,32 @@ __device__ __forceinline__ VI wave_argmin(VI a)
 {
     return wave_allreduce(a, [](VI x, VI y) { return vi_less(y.v, y.i, x.v, x.i) ? y : x; });
 }
+// min / max of doubles inside a reduction (numbers or infinities, +-inf the identity; a quiet NaN loses to a number as in
+// fmin / fmax): the bare instruction, without the two quieting v_max_f64 that fmin() / fmax() prepend to operands whose
+// origin the compiler does not know (lane moves)
+__device__ __forceinline__ double lpx_min_f64(double x, double y)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ double lpx_max_f64(double x, double y)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 __device__ __forceinline__ double wave_min(double v)
 {
-    return wave_allreduce(v, [](double x, double y) { return fmin(x, y); });
+    return wave_allreduce(v, [](double x, double y) { return lpx_min_f64(x, y); });
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-    return wave_allreduce(v, [](double x, double y) { return fmax(x, y); });
+    return wave_allreduce(v, [](double x, double y) { return lpx_max_f64(x, y); });
+}
+__device__ __forceinline__ int wave_imin32(int v)
+{
+    return wave_allreduce(v, [](int x, int y) { return y < x ? y : x; });
 }
 __device__ __forceinline__ int64_t wave_imin(int64_t v)
 {

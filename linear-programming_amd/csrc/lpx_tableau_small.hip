@@ -43,51 +43,6 @@ __device__ long long g_ts_entry, g_ts_exit;
 //     rows and slots, and a spilled scalar is a VALU lane move per use).
 #define TS_KEEP_BRANCH() asm volatile("" ::: "memory") /* keeps a wave-uniform branch a branch (no if-conversion) */
 
-// Lane moves whose every destination lane has a source (quad_perm, row_ror with full masks): the "old" operand of the DPP
-// move is dead, and naming none saves the copy (and its wait states) that tying it to the source costs (lpx_dpp_move)
-template <typename T, int CTRL>
-__device__ __forceinline__ T ts_dpp(T v)
-{
-    LpxWords<T> u;
-    __builtin_memcpy(&u, &v, sizeof(T));
-#pragma unroll
-    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = __builtin_amdgcn_mov_dpp(u.w[k], CTRL, 0xf, 0xf, false);
-    T r;
-    __builtin_memcpy(&r, &u, sizeof(T));
-    return r;
-}
-template <typename T, typename Op>
-__device__ __forceinline__ T ts_row16(T v, Op op)
-{
-    v = op(v, ts_dpp<T, LPX_DPP_QUAD_XOR1>(v));
-    v = op(v, ts_dpp<T, LPX_DPP_QUAD_XOR2>(v));
-    v = op(v, ts_dpp<T, LPX_DPP_ROW_ROR4>(v));
-    return op(v, ts_dpp<T, LPX_DPP_ROW_ROR8>(v));
-}
-template <typename T, typename Op>
-__device__ __forceinline__ T ts_wave(T v, Op op)
-{
-    v = ts_row16(v, op);
-    T a, b;
-    lpx_lane_swap<T, false>(v, a, b);
-    v = op(a, b);
-    lpx_lane_swap<T, true>(v, a, b);
-    return op(a, b);
-}
-// min / max of doubles that are numbers or infinities (reduction operands here: ratios, reduced costs, column entries, with
-// +-inf as the identity): the bare instruction, without the quieting fmin() / fmax() prepend to operands of unknown origin
-__device__ __forceinline__ double ts_min(double x, double y)
-{
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ double ts_max(double x, double y)
-{
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
 struct TsCand { // pricing, Dantzig's rule: the smallest reduced cost, its variable, its slot
     double mn;
     int var, slot;
@@ -248,15 +203,15 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         if (dantzig) {
             TsCand c{LPX_INF, TS_NOVAR, -1};
             if (inrc && ts_less(rc, var, c.mn, c.var)) c = TsCand{rc, var, t};
-            c = ts_wave(c, [](TsCand x, TsCand y) { return ts_less(y.mn, y.var, x.mn, x.var) ? y : x; });
+            c = wave_allreduce(c, [](TsCand x, TsCand y) { return ts_less(y.mn, y.var, x.mn, x.var) ? y : x; });
             if (lane == 0) sh_price[ph][wave] = c;
             __syncthreads();
             // the sixteen partials: smallest cost, smallest id among the waves that have it, and that wave's slot
             const TsCand *wc = &sh_price[ph][lane & (TS_WAVES - 1)];
             const double wmn = wc->mn;
             const int wvar = wc->var;
-            const double mn = ts_row16(wmn, [](double x, double y) { return ts_min(x, y); });
-            const int minvar = ts_row16(wmn == mn ? wvar : TS_NOVAR, [](int x, int y) { return y < x ? y : x; });
+            const double mn = row16_allreduce(wmn, [](double x, double y) { return lpx_min_f64(x, y); });
+            const int minvar = row16_allreduce(wmn == mn ? wvar : TS_NOVAR, [](int x, int y) { return y < x ? y : x; });
             const unsigned who = (unsigned)__ballot(wmn == mn && wvar == minvar) & 0xffffu;
             optimal = lpx_is_optimal_min(mn);
             slot = sh_price[ph][who ? __ffs(who) - 1 : 0].slot;
@@ -265,7 +220,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
             // the loop ends when min rc >= -atol (lpx_is_optimal_min), i.e. when no reduced cost lies below -atol
             const int myvar = (inrc && rc < 0.0) ? var : TS_NOVAR; // first negative index: smallest variable id (ids are distinct)
             TsBland c;
-            c.var = ts_wave(myvar, [](int x, int y) { return y < x ? y : x; });
+            c.var = wave_allreduce(myvar, [](int x, int y) { return y < x ? y : x; });
             c.slot = (wave << 6) + __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(myvar == c.var)) - 1);
             c.live = __ballot(inrc && rc < -LPX_ATOL) != 0ull;
             c.pad = 0;
@@ -274,7 +229,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
             // the sixteen partials: smallest id, the wave that has it (ids are distinct), its slot
             const TsBland *wb = &sh_bland[ph][lane & (TS_WAVES - 1)];
             const int wvar = wb->var;
-            const int minvar = ts_row16(wvar, [](int x, int y) { return y < x ? y : x; });
+            const int minvar = row16_allreduce(wvar, [](int x, int y) { return y < x ? y : x; });
             const unsigned who = (unsigned)__ballot(wvar == minvar) & 0xffffu;
             optimal = ((unsigned)__ballot(wb->live != 0) & 0xffffu) == 0u;
             slot = sh_bland[ph][who ? __ffs(who) - 1 : 0].slot;
@@ -328,7 +283,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         // max d <= 0 (:144-147), i.e. when no entry is positive
         d_tested = inx ? di : -LPX_INF;
         const double th = inx ? lpx_psd(xb, di, P == 0 && f32) : LPX_INF;
-        const double thw = ts_wave(th, [](double x, double y) { return ts_min(x, y); });
+        const double thw = wave_allreduce(th, [](double x, double y) { return lpx_min_f64(x, y); });
         const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(th == thw)) - 1);
         // the cross-lane reads stay OUTSIDE the lane-0 branch: under it the source lane is inactive and the read undefined
         const TsRatio wrec{thw, tf_readlane_f64(di, src), tf_readlane_f64(xb, src), (wave << 6) + src,
@@ -338,7 +293,7 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
         // the sixteen partials: the smallest ratio, the FIRST wave that has it (rows ascend with the wave), its record
         const TsRatio *wr = &sh_ratio[ph][lane & (TS_WAVES - 1)];
         const double wth = wr->th;
-        const double thmin = ts_row16(wth, [](double x, double y) { return ts_min(x, y); });
+        const double thmin = row16_allreduce(wth, [](double x, double y) { return lpx_min_f64(x, y); });
         const unsigned who = (unsigned)__ballot(wth == thmin) & 0xffffu;
         const bool anypos = ((unsigned)__ballot(wr->pos != 0) & 0xffffu) != 0u;
         TS_STAMP(3);
@@ -428,10 +383,10 @@ __device__ __forceinline__ void ts_decide(const TsArgs &a)
     // leaves them: the loop may end on the first pricing of the next one, which then has no ratio test of its own to report
     const TsArgs &z = sh_args;
     TsMinMax mm{rc_priced, d_tested};
-    mm = ts_wave(mm, [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
+    mm = wave_allreduce(mm, [](TsMinMax x, TsMinMax y) { return TsMinMax{lpx_min_f64(x.mn, y.mn), lpx_max_f64(x.mx, y.mx)}; });
     if (lane == 0) sh_red[wave] = mm;
     __syncthreads();
-    mm = ts_row16(sh_red[lane & (TS_WAVES - 1)], [](TsMinMax x, TsMinMax y) { return TsMinMax{ts_min(x.mn, y.mn), ts_max(x.mx, y.mx)}; });
+    mm = row16_allreduce(sh_red[lane & (TS_WAVES - 1)], [](TsMinMax x, TsMinMax y) { return TsMinMax{lpx_min_f64(x.mn, y.mn), lpx_max_f64(x.mx, y.mx)}; });
     // ---- the block's pairs and the state the next launch (or the caller) starts from
     if (inrow) {
         double *dst = z.b.Et + t;
