@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
         const double e = ((t == r) ? 1.0 : -d) / dr; // :236-244: 1/d_r or (-d_i)/d_r (lanes >= m: d = 0, e = -0, rows stay 0)
         const double em = (-rcj) / dr;               // eliminates the entering column's reduced cost
         const double xr = tb_readlane(xb, r);
-        if (row) xb = (t == r) ? e * xr : fma(e, xr, xb); // :251-253
+        if (row) xb = fma(e, xr, (t == r) ? -0.0 : xb); // :251-253 (fma on -0.0 = the plain product)
         const int64_t leaving = (int64_t)__builtin_amdgcn_readlane((int)bas, r); // variable ids < 2^31 here (n <= 128)
         if (!DUAL) { // this column's pivot-row entry
             switch (r) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64, MR <= 32 ? 4 : 3) void k_batched_tab(TabBatchAr
             const int rchunk = r >> 3;
 #pragma unroll
             for (int c = 0; c < MR / 8; ++c) {
-                if (rchunk == c) {
+                if (rchunk == c) { // (clearing the row inside the switch that reads it costs 3x: 64 register merges per case)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[8 * c + j] = (8 * c + j == r) ? -0.0 : x[8 * c + j];
                 }
