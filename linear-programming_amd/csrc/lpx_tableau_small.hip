@@ -1,14 +1,15 @@
 // lpx_tableau_small.hip -- the deferred-update chain for LAUNCH-BOUND tableaus (BASELINE config 2: 1000 x 2000).
 //
 // At 1001 x 1001 a pass over the tableau costs 2-3 us and every kernel boundary as much again: the single-launch chain
-// (k_t_fused) pays one boundary per pivot (6.7 us per pivot, 148 k pivots/s).  Here ONE launch carries a whole block of
+// (k_t_fused) pays one boundary per pivot (6.7 us per pivot, 148 k pivots/s; this chain: 4.8 us, 207 k).  Here ONE launch carries a whole block of
 // TS_KB pivots, in two roles (the pipelined chain of lpx_tableau_blocked.hpp folded into a kernel):
 //   * workgroup 0 DECIDES block k+1 -- all of its TS_KB pivots, one after the other, with no kernel boundary and no other
 //     workgroup to wait for: thread t owns row t and column t of the tableau "as the pending updates leave it", keeps its
 //     row's multipliers e_u[t] and its column's pivot-row entries R_u[t] of both blocks IN REGISTERS, and everything a pivot
 //     exchanges (pricing, ratio test, the pivot row's multipliers, the entering column's row entries) goes through LDS:
 //     two gathers from the stale tableau (the entering column, the pivot row) are the only memory round trips of a pivot;
-//   * the other workgroups are the PASS of block k: T_old -> T_new with block k's pairs (tb2_flush_body, lpx_tb_flush.hpp).
+//   * the other workgroups are the PASS of block k: T_old -> T_new with block k's pairs (ts_pass below: tb_apply's
+//     expressions, lpx_tb_flush.hpp).
 // Both read the same stale buffer, neither reads what the other writes, and the next launch starts when both are done:
 // the launch boundary is the only grid-wide synchronisation of TS_KB pivots.  Same expressions in the same order as
 // k_tb_column / k_tb_prepare and hence as one update per pivot (primal_solvers.py:135-167, :217-253): bit-identical.
@@ -29,8 +30,9 @@ __device__ long long g_ts_entry, g_ts_exit;
 
 // One CU issues every instruction of the deciding workgroup 16 times (16 waves, four to a SIMD): a pivot's time is its
 // two gathers plus 16 x 4 cycles per instruction of the thread program, so the program is written for its instruction count:
-//   * what is the same for every thread (pivot rows and slots of the pending pairs, the pivot's own row / slot) lives in
-//     scalar registers -- a pair's row and slot in one -- and a test on it is a scalar branch;
+//   * what is the same for every thread (the pivot's own row / slot, which pending pairs concern this wave) lives in
+//     scalar registers, and a test on it is a scalar branch; the pending pairs' rows and slots themselves sit in ONE
+//     vector register (lane u: pair u), read by ballot (does any pair rewrite this column?) or v_readlane (rare paths);
 //   * the one thread of 1024 a select singles out (the pivot row in the column chain, the rewritten slot in the row chain)
 //     costs its WAVE a select and the other fifteen waves a scalar compare;
 //   * a reduction carries what the DECISION needs and nothing else: Bland's rule the smallest negative-cost variable id
