@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Random shapes through the carried-tableau solvers (primal and dual rules, condensed and full layout, one-launch chain,
-the in-place chains and the deferred-update chains with blocks of 8 / 16 / 32, solve() in pieces) against the oracle's tableau loops: pivot log, x, iteration counts, status.
+"""Random shapes through the carried-tableau solvers (primal and dual rules, condensed and full layout, the chain of one
+launch per 8 pivots, the one-launch chain, the in-place chains and the deferred-update chains with blocks of 8 / 16 / 32 --
+in place and pipelined --, solve() in pieces) against the oracle's tableau loops: pivot log, x, iteration counts, status.
 GPU box: python3 tools/fuzz_tableau.py [cases] [seed]"""
 import os
 import sys
@@ -25,9 +26,13 @@ def main():
         condensed = bool(rng.random() < 0.6)
         fused = bool(rng.random() < 0.7)
         os.environ["LPX_TABLEAU_FUSED"] = "1" if fused else "0"
+        small = bool(fused and rng.random() < 0.6)  # one launch per 8 pivots (primal rules, shapes that fit one workgroup)
+        os.environ["LPX_TABLEAU_SMALL_CHAIN"] = "1" if small else "0"
         block = int(rng.choice([0, 8, 16, 32], p=[0.4, 0.2, 0.2, 0.2]))  # > 0: deferred updates, forced on at any size
         os.environ["LPX_TABLEAU_BLOCK"] = str(block)
         os.environ["LPX_TABLEAU_BLOCK_MIN_MB"] = "0" if block else "1000000"
+        pipe = bool(block and rng.random() < 0.5)  # the pass beside the next block's decisions (second buffer forced on)
+        os.environ["LPX_TABLEAU_PIPELINE_MIN_MB"] = "0" if pipe else "-1"
         if block:
             os.environ["LPX_TB_ROWS"] = str(int(rng.choice([0, 1, 7, 64, 200])))
         seed = 1000 + it
@@ -52,7 +57,7 @@ def main():
                 ok, note = False, f"GPU constructor raised {type(e).__name__}, oracle did not"
             except Exception:
                 note = f"both constructors raise ({type(e).__name__})"
-            print(f"{it:3d}: {kind:6s} {m:3d}x{n:4d} cond={int(condensed)} fused={int(fused)} block={block:2d} {note} {'ok' if ok else 'MISMATCH'}", flush=True)
+            print(f"{it:3d}: {kind:6s} {m:3d}x{n:4d} cond={int(condensed)} fused={int(fused)} small={int(small)} block={block:2d} pipe={int(pipe)} {note} {'ok' if ok else 'MISMATCH'}", flush=True)
             bad += not ok
             continue
         done = 0
@@ -73,7 +78,7 @@ def main():
             ok = ok and bool(res.optimum) == (r.status == O.OPTIMAL)
             if r.status != O.RUNNING:
                 break
-        print(f"{it:3d}: {kind:6s} {m:3d}x{n:4d} cond={int(condensed)} fused={int(fused)} block={block:2d} pivots={len(s.pivot_log()):5d} {note} "
+        print(f"{it:3d}: {kind:6s} {m:3d}x{n:4d} cond={int(condensed)} fused={int(fused)} small={int(small)} block={block:2d} pipe={int(pipe)} pivots={len(s.pivot_log()):5d} {note} "
               f"{'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
     print("failures:", bad)
