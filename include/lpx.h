@@ -145,7 +145,7 @@ typedef struct lpx_tableau {
     /* Optional second buffer of the size of T ((m+1) x ld doubles, 16-byte aligned), or NULL.  With it, lpx_tableau_iterate
      * and lpx_tableau_dual_iterate run tableaus of up to 16384 rows and 32767 columns as ONE launch per pivot: the
      * tableau ping-pongs between T and T_alt while lookahead workgroups of the same launch prepare the next pivot's
-     * decisions (lpx_tableau.hip); primal tableaus of up to 1023 rows and 1022 carried columns as one launch per 8
+     * decisions (lpx_tableau.hip); primal tableaus of up to 1023 rows and 1023 carried columns as one launch per 8
      * pivots (lpx_tableau_chain_kind, LPX_CHAIN_SMALL).  Large tableaus (lpx_tableau_pipelined() != 0) use it for the PIPELINED deferred-update
      * chain instead: the pass over the tableau streams T -> T_alt (then back) while the next block's pivots are decided
      * beside it.  The state is in T again whenever a call's work has drained; T_alt's contents are scratch between
@@ -299,7 +299,7 @@ int lpx_tableau_pipelined(const lpx_tableau *s);
  *   LPX_CHAIN_EAGER      column -> prepare -> K1, one rank-1 update of T per pivot, in place
  *   LPX_CHAIN_FUSED      one launch per pivot on two alternating buffers (T_alt set, up to 16384 rows)
  *   LPX_CHAIN_SMALL      one launch per block of 8 pivots: one workgroup decides the block while the others apply the
- *                        previous one (T_alt set, m + 1 <= 1024 and n + 2 <= 1024: launch-bound tableaus, BASELINE config 2)
+ *                        previous one (T_alt set, m + 1 <= 1024 and n + 1 <= 1024: launch-bound tableaus, BASELINE config 2)
  *   LPX_CHAIN_DEFERRED   deferred updates, decisions then one pass per block, in place (see lpx_tableau_block_size)
  *   LPX_CHAIN_PIPELINED  deferred updates, the pass beside the next block's decisions (see lpx_tableau_pipelined) */
 #define LPX_CHAIN_EAGER 0

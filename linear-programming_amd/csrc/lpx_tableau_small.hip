@@ -13,7 +13,7 @@
 // Both read the same stale buffer, neither reads what the other writes, and the next launch starts when both are done:
 // the launch boundary is the only grid-wide synchronisation of TS_KB pivots.  Same expressions in the same order as
 // k_tb_column / k_tb_prepare and hence as one update per pivot (primal_solvers.py:135-167, :217-253): bit-identical.
-// Shapes: m + 1 <= 1024 rows and n + 2 <= 1024 carried columns (one workgroup holds a row and a column per thread).
+// Shapes: m + 1 <= 1024 rows and n + 1 <= 1024 carried columns, x_B included (one workgroup holds a row and a column per thread).
 #include "lpx_tb_flush.hpp"
 #include "lpx_tableau_dev.hpp"
 #include "lpx_tableau_small_decl.hpp"

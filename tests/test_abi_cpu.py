@@ -128,3 +128,48 @@ def test_selfcheck_without_a_device_is_an_error_code_not_a_crash():
     L = _lib.load()
     n = C.c_int64(-1)
     assert L.lpx_selfcheck(C.byref(n)) in (-2, -1) and n.value == 0 and L.lpx_last_error()
+
+
+def test_chain_selection_is_host_logic_and_follows_the_documented_thresholds(monkeypatch):
+    """lpx_tableau_chain_kind / lpx_tableau_block_size / lpx_tableau_pipelined read sizes, pointers and the environment
+    only (no device): which launch chain lpx_tableau_iterate runs for a state, as include/lpx.h documents it."""
+    import ctypes as C
+
+    from linprog_amd import _lib
+
+    for name in ("LPX_TABLEAU_FUSED", "LPX_TABLEAU_SMALL_CHAIN", "LPX_TABLEAU_BLOCK", "LPX_TABLEAU_BLOCK_MIN_MB",
+                 "LPX_TABLEAU_PIPELINE_MIN_MB"):
+        monkeypatch.delenv(name, raising=False)
+    L = C.CDLL(_lib.LIB_PATH)
+    L.lpx_tableau_chain_kind.argtypes = L.lpx_tableau_block_size.argtypes = L.lpx_tableau_pipelined.argtypes = [C.POINTER(_lib.LpxTableau)]
+    L.lpx_tableau_block_size.restype = C.c_int64
+
+    def state(m, carried, condensed=True, alt=True, ratio=_lib.RATIO_TEXTBOOK):
+        s = _lib.LpxTableau()
+        s.m, s.n, s.ld, s.col0, s.n_global = m, carried, carried + 2, 0, (carried + m if condensed else carried)
+        s.T = 0x1000  # never dereferenced by these calls
+        s.T_alt = 0x2000 if alt else None
+        s.slot_var = s.var_slot = (0x3000 if condensed else None)
+        s.ratio_rule = ratio
+        return s
+
+    kind = lambda s: L.lpx_tableau_chain_kind(C.byref(s))
+    assert kind(state(1000, 1000)) == _lib.CHAIN_SMALL  # BASELINE config 2
+    assert kind(state(1023, 1023)) == _lib.CHAIN_SMALL and kind(state(1024, 1000)) == _lib.CHAIN_FUSED
+    assert kind(state(64, 1024)) == _lib.CHAIN_FUSED  # one carried column too many for a workgroup
+    assert kind(state(1000, 1000, alt=False)) == _lib.CHAIN_EAGER
+    assert kind(state(1000, 1000, ratio=_lib.RATIO_HARRIS)) == _lib.CHAIN_EAGER
+    assert kind(state(300, 700, condensed=False)) == _lib.CHAIN_SMALL
+    big = state(20000, 20000)  # BASELINE config 4, condensed: 3.2 GB
+    assert kind(big) == _lib.CHAIN_PIPELINED and L.lpx_tableau_block_size(C.byref(big)) == 32 and L.lpx_tableau_pipelined(C.byref(big)) == 1
+    assert kind(state(20000, 20000, alt=False)) == _lib.CHAIN_DEFERRED
+    mid = state(10000, 10000)  # 800 MB: deferred in place whether or not there is a second buffer
+    assert kind(mid) == _lib.CHAIN_DEFERRED and L.lpx_tableau_pipelined(C.byref(mid)) == 0
+    assert L.lpx_tableau_block_size(C.byref(state(3000, 3000))) == 16 and L.lpx_tableau_block_size(C.byref(state(2000, 2000))) == 0
+    monkeypatch.setenv("LPX_TABLEAU_SMALL_CHAIN", "0")
+    assert kind(state(1000, 1000)) == _lib.CHAIN_FUSED
+    monkeypatch.setenv("LPX_TABLEAU_FUSED", "0")
+    assert kind(state(1000, 1000)) == _lib.CHAIN_EAGER
+    monkeypatch.setenv("LPX_TABLEAU_PIPELINE_MIN_MB", "-1")
+    assert kind(big) == _lib.CHAIN_DEFERRED
+    assert L.lpx_tableau_chain_kind(None) == -1

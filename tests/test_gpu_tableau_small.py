@@ -33,9 +33,9 @@ def ctrl_of(solver):
 
 @pytest.mark.parametrize("pricing", ["first_negative", "dantzig"])
 @pytest.mark.parametrize("m,n,condensed,seed", [(300, 700, True, 5), (300, 700, False, 5), (530, 1061, True, 6), (1000, 2000, True, 0),
-                                                (1023, 2045, True, 2), (7, 20, True, 1), (64, 1020, False, 3)])
+                                                (1023, 2045, True, 2), (7, 20, True, 1), (64, 1020, False, 3), (40, 1063, True, 4)])
 def test_small_chain_bit_exact(m, n, condensed, seed, pricing, monkeypatch):
-    """Shapes up to the chain's limits (1024 rows with the cost row, 1024 carried columns with x_B), both layouts, both
+    """Shapes up to the chain's limits (1024 rows with the cost row, 1024 carried columns with x_B: 40 x 1063 carries 1023), both layouts, both
     pricing rules, calls that are no multiple of the block, end on either buffer and follow one another."""
     from linprog_amd import _lib
     from linprog_amd.tableau import PrimalTableauSimplexSolver
@@ -134,5 +134,5 @@ def test_small_chain_limits():
 
     c, A, b, basis = gen.gen_primal(1024, 2050, 1)
     assert chain_kind(PrimalTableauSimplexSolver(c, A, b, basis)) != _lib.CHAIN_SMALL
-    c, A, b, basis = gen.gen_primal(64, 1200, 1)  # 1136 carried columns
+    c, A, b, basis = gen.gen_primal(64, 1088, 1)  # 1024 carried columns: one too many
     assert chain_kind(PrimalTableauSimplexSolver(c, A, b, basis)) != _lib.CHAIN_SMALL
