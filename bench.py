@@ -196,7 +196,7 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     # The update kernel is timed with HIP events on the launch stream.  At HBM-bound sizes they are recorded inside the
     # timed region.  Launch-bound sizes are replayed as hipGraphs (event records cannot ride along), so there the kernel
     # is timed in a separate eager pass of further pivots afterwards.
-    events_in_timed = m >= 10000 or group is not None
+    events_in_timed = (m >= 10000 or group is not None) and os.environ.get("LPX_BENCH_K1_EVENTS", "1") != "0"
     _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, torch.cuda.current_stream().cuda_stream))
     eng.enqueue(W_piv)
     barrier()

@@ -376,8 +376,10 @@ class OraclePrimalDual:
 
     The restricted primal is the full problem [A | I] with inadmissible columns excluded (Bland order over
     the admissible columns followed by the artificials is the order of the reference's compacted matrix).
-    The restricted dual y_rp = c_B B^-1 uses the inner solver's float64 inverse (the reference takes a fresh
-    float32 LAPACK inverse at :433, so its y_rp agrees to float32 accuracy only).
+    The restricted dual y_rp = c_B B^-1 uses the inner solver's float64 product-form inverse; the reference takes a
+    fresh LAPACK inverse at :433 -- of a FLOAT64 matrix (A_rp = np.hstack([A float32, np.eye(m)]) is float64, :411-413;
+    recorded per case in tests/golden/primal_dual.json, "dual_step_inverse_dtypes"), so the two agree to rounding:
+    the golden's last y @ A is matched to 1e-9, every outer iteration's admissible set and inner pivot exactly.
     """
 
     def __init__(self, c, A, b):

@@ -350,20 +350,54 @@ def phase_one_cases():
     return out
 
 
+class DualStepSpy:
+    """What the dual step of PrimalDualAlgorithm.solve really computes with (special_solvers.py:405, :430-433): the dtype
+    of every matrix handed to np.linalg.inv (the restricted primal's constructor inverts twice in float32; the dual step's
+    FRESH inverse is float64, because np.hstack([A float32, np.eye(m)]) at :411-413 is a float64 array) and the vector
+    y @ A of every admissibility test (:405) -- the last one carries every dual step of the run."""
+
+    def __enter__(self):
+        self.inv_dtypes, self.adm_sizes, self.yA = [], [], None
+        self._inv, self._isclose = np.linalg.inv, np.isclose
+
+        def inv(a):
+            self.inv_dtypes.append((sys._getframe(1).f_code.co_name, str(np.asarray(a).dtype)))  # (calling function, dtype)
+            return self._inv(a)
+
+        def isclose(a, b, *args, **kw):
+            out = self._isclose(a, b, *args, **kw)
+            if np.ndim(a) == 1 and np.ndim(b) == 1 and len(a) > 1:  # :405 (the optimality tests compare scalars)
+                self.yA = np.array(a, dtype=float)
+                self.adm_sizes.append(int(out.sum()))
+            return out
+
+        np.linalg.inv, np.isclose = inv, isclose
+        return self
+
+    def __exit__(self, *a):
+        np.linalg.inv, np.isclose = self._inv, self._isclose
+
+
 def primal_dual_cases():
     out = []
     for m in (4, 8, 16, 32, 64, 128):  # 64: the size bench.py --workload config5 times; 128: beyond the one-launch kernel
         for seed in range(2):
             t0 = time.time()
             c, A, b, _ = gen.gen_dual(m, 2 * m, seed)
-            with Trace() as tr:
+            with Trace() as tr, DualStepSpy() as spy:
                 try:
                     res = special_solvers.PrimalDualAlgorithm(c, A, b).solve(100000, 100000)
                     r = _res(res, tr.events)
                 except Exception as e:
                     r = _res(None, tr.events, type(e).__name__)
+            # per outer iteration: the inner solver's __init__ and _check_basis_feasibility, then solve's own at :433
+            r["dual_step_inverse_dtypes"] = sorted(set(d for f, d in spy.inv_dtypes if f == "solve"))
+            r["constructor_inverse_dtypes"] = sorted(set(d for f, d in spy.inv_dtypes if f != "solve"))
+            r["adm_sizes"] = spy.adm_sizes
+            r["yA_last"] = lst(spy.yA)
             out.append(dict(gen="gen_dual", solver="PrimalDualAlgorithm", m=m, n=2 * m, seed=seed, ref=r))
-            print(f"  primal-dual m={m} seed={seed}: iters={r.get('iters')} {time.time() - t0:.1f}s", flush=True)
+            print(f"  primal-dual m={m} seed={seed}: iters={r.get('iters')} dual-step inverse {r['dual_step_inverse_dtypes']} "
+                  f"{time.time() - t0:.1f}s", flush=True)
     return out
 
 

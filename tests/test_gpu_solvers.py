@@ -229,6 +229,9 @@ def test_primal_dual_matches_reference(cs):
     assert res.basis.tolist() == ref["basis"]
     assert_close(res.x, ref["x"], "x")
     assert_close(res.cost, ref["cost"], "cost")
+    if "yA_last" in ref:  # the dual vector itself (special_solvers.py:430-444; the reference's fresh inverse is float64)
+        assert [len(a) for a in s.admissible_sets] == ref["adm_sizes"]
+        assert_close(s.y[: s.m] @ np.asarray(s.A, dtype=np.float64), ref["yA_last"], "y @ A")
     if "optimal_bfs" in cs:  # tests/test_primal_dual_algorithm.py:11-16: exact
         assert np.array_equal(res.x, np.array(cs["optimal_bfs"], dtype=float))
 
@@ -357,6 +360,8 @@ def test_primal_dual_one_launch_matches_reference(cs):
     assert res.basis.tolist() == ref["basis"]
     assert_close(res.x, ref["x"], "x")
     assert_close(res.cost, ref["cost"], "cost")
+    if "yA_last" in ref:  # the one-launch kernel's dual vector against the reference's last admissibility test
+        assert_close(s.y[: s.m] @ np.asarray(s.A, dtype=np.float64), ref["yA_last"], "y @ A")
     if "optimal_bfs" in cs:  # tests/test_primal_dual_algorithm.py:11-16 asserts exact equality
         assert np.array_equal(res.x, np.array(cs["optimal_bfs"], dtype=float))
 
