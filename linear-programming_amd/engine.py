@@ -30,6 +30,14 @@ class RevisedEngine:
         # B^-1 is the matrix K1 streams: 4-KiB-aligned rows once it is large (see tableau.row_alignment)
         pad = lambda cols, unit: roundup(cols, 4096 // unit if cols * unit >= 32768 else (128 // unit if cols * unit >= 1024 else 16 // unit))
         self.ldA, self.ldAt, self.ldB = pad(n, 4), pad(m, 4), pad(m, 8)
+        self.log_cap = int(log_cap)
+        self.naive = bool(naive)
+        self.host_ctrl = _lib.LpxCtrl()
+        self._result = None  # host copy of the result region after a small solve (arena states only)
+        self.arena = None
+        if not hasattr(A32, "A_dev") and self._arena_bytes(lb is not None) <= self.ARENA_MAX:
+            self._init_arena(c32, A32, b32, basis, inv0, bfs0, var_state, lb, ub)
+            return
         if hasattr(A32, "A_dev"):
             if A32.A_dev.shape[1] == self.ldA:
                 self.A = A32.A_dev
@@ -52,34 +60,129 @@ class RevisedEngine:
         self.lb = None if lb is None else to_device(np.asarray(lb, dtype=np.float64))
         self.ub = None if ub is None else to_device(np.asarray(ub, dtype=np.float64))
         self.ctrl = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        self.log_cap = int(log_cap)
         self.log = torch.zeros((max(self.log_cap, 1), 3), dtype=torch.int64, device="cuda")
         ws_bytes = self.lib.lpx_revised_workspace_bytes(m, n)
         self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
         self.x = torch.zeros(n, dtype=torch.float64, device="cuda")
         self.cost = torch.zeros(1, dtype=torch.float64, device="cuda")
-        self.host_ctrl = _lib.LpxCtrl()
-
-        s = self.s = _lib.LpxRevised()
-        s.m, s.n, s.ldA, s.ldAt, s.ldB = m, n, self.ldA, self.ldAt, self.ldB
-        s.A, s.At, s.b, s.c = self.A.data_ptr(), self.At.data_ptr(), self.b.data_ptr(), self.c.data_ptr()
-        s.Binv, s.xB, s.basis = self.Binv.data_ptr(), self.xB.data_ptr(), self.basis.data_ptr()
-        s.var_state = self.var_state.data_ptr()
-        s.lb = None if self.lb is None else self.lb.data_ptr()
-        s.ub = None if self.ub is None else self.ub.data_ptr()
-        s.ctrl = self.ctrl.data_ptr()
-        s.log = self.log.data_ptr() if self.log_cap > 0 else None
-        s.log_cap = self.log_cap
-        s.workspace, s.workspace_bytes = self.workspace.data_ptr(), ws_bytes
-        self.naive = bool(naive)
         if self.naive:  # float32 re-inversion scratch: W = [B | I]
             nbytes = self.lib.lpx_naive_workspace_bytes(m)
             self.naive_workspace = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
-            s.naive_workspace, s.naive_workspace_bytes = self.naive_workspace.data_ptr(), nbytes
-        _lib.check(self.lib.lpx_ctrl_init(s.ctrl, 1, stream_ptr()))
+        self._bind_state(ws_bytes)
+        _lib.check(self.lib.lpx_ctrl_init(self.s.ctrl, 1, stream_ptr()))
+
+    #: states up to this many bytes live in ONE device allocation filled by ONE upload (a lone small LP is latency-bound:
+    #: a dozen allocations, fills and uploads cost ~0.3 ms, several times the solve); larger ones keep a tensor per array
+    ARENA_MAX = (4 << 20) if os.environ.get("LPX_ARENA", "1") != "0" else -1  # LPX_ARENA=0: a tensor per array
+
+    def _arena_items(self, bounded):
+        """(name, dtype, shape) of every array of the state, in arena order; the RESULT region -- control block, cost, x,
+        basis, var_state, x_B -- is contiguous so that one download brings back everything solve() returns."""
+        m, n = self.m, self.n
+        ws = int(self.lib.lpx_revised_workspace_bytes(m, n))
+        items = [("ctrl", np.uint8, (128,)), ("cost", np.float64, (1,)), ("x", np.float64, (n,)), ("basis", np.int64, (m,)),
+                 ("var_state", np.int32, (n,)), ("xB", np.float64, (m,)),
+                 ("A", np.float32, (m, self.ldA)), ("At", np.float32, (n, self.ldAt)), ("b", np.float32, (m,)),
+                 ("c", np.float32, (n,)), ("Binv", np.float64, (m, self.ldB)),
+                 ("log", np.int64, (max(self.log_cap, 1), 3)), ("workspace", np.uint8, (ws,))]
+        if bounded:
+            items += [("lb", np.float64, (n,)), ("ub", np.float64, (n,))]
+        if self.naive:
+            items.append(("naive_workspace", np.uint8, (int(self.lib.lpx_naive_workspace_bytes(m)),)))
+        return items
+
+    def _arena_layout(self, bounded):
+        offs, off = {}, 0
+        for name, dt, shape in self._arena_items(bounded):
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            offs[name] = (off, nb, dt, shape)
+            off += roundup(max(nb, 1), 256)
+        return offs, off
+
+    def _arena_bytes(self, bounded):
+        return self._arena_layout(bounded)[1]
+
+    def _init_arena(self, c32, A32, b32, basis, inv0, bfs0, var_state, lb, ub):
+        torch = self.torch
+        m, n = self.m, self.n
+        offs, total = self._arena_layout(lb is not None)
+        buf = np.zeros(total, dtype=np.uint8)
+
+        def host(name):
+            o, nb, dt, shape = offs[name]
+            return np.ndarray(shape, dtype=dt, buffer=buf, offset=o)
+
+        A32 = A32.astype(np.float32, copy=False)
+        host("A")[:, :n] = A32
+        host("At")[:, :m] = A32.T
+        host("b")[:] = b32
+        host("c")[:] = c32
+        host("Binv")[:, :m] = inv0
+        host("xB")[:] = bfs0
+        basis = np.asarray(basis, dtype=np.int64)
+        host("basis")[:] = basis
+        if var_state is None:
+            vs = host("var_state")
+            vs[:] = _lib.VS_LOWER
+            vs[basis] = _lib.VS_BASIC
+        else:
+            host("var_state")[:] = var_state
+        if lb is not None:
+            host("lb")[:] = lb
+            host("ub")[:] = ub
+        c0 = _lib.LpxCtrl()  # what lpx_ctrl_init(ctrl, 1) leaves
+        c0.f32_phase, c0.enter_j, c0.leave_r, c0.leave_var = 1, -1, -1, -1
+        host("ctrl")[:] = np.frombuffer(bytes(c0), dtype=np.uint8)
+        self.arena = torch.from_numpy(buf).to("cuda")  # one allocation, one upload
+        self._arena_offs = offs  # tensor views of the arrays are made on first use (__getattr__): most are never touched
+        if lb is None:
+            self.lb = self.ub = None
+        o_last, nb_last = offs["xB"][0], offs["xB"][1]
+        self._result_span = (offs["ctrl"][0], o_last + nb_last)
+        self._result_offs = {k: offs[k] for k in ("ctrl", "cost", "x", "basis", "var_state", "xB")}
+        base = self.arena.data_ptr()
+        self._bind_state(offs["workspace"][1], {k: base + v[0] for k, v in offs.items()})
+
+    _TORCH_DTYPES = {np.uint8: "uint8", np.float32: "float32", np.float64: "float64", np.int64: "int64", np.int32: "int32"}
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: an array of an arena state that nobody has asked for yet
+        offs = self.__dict__.get("_arena_offs")
+        if offs is None or name not in offs:
+            raise AttributeError(name)
+        o, nb, dt, shape = offs[name]
+        t = self.arena[o:o + nb]
+        t = (t if dt is np.uint8 else t.view(getattr(self.torch, self._TORCH_DTYPES[dt]))).view(shape)
+        setattr(self, name, t)
+        return t
+
+    def _bind_state(self, ws_bytes, ptrs=None):
+        """Fill the C struct; ptrs: device addresses by array name (arena states), else taken from the tensors."""
+        m, n = self.m, self.n
+        if ptrs is None:
+            names = ["A", "At", "b", "c", "Binv", "xB", "basis", "var_state", "ctrl", "log", "workspace", "x", "cost"]
+            names += ["lb", "ub"] if self.lb is not None else []
+            names += ["naive_workspace"] if self.naive else []
+            ptrs = {k: getattr(self, k).data_ptr() for k in names}
+        s = self.s = _lib.LpxRevised()
+        s.m, s.n, s.ldA, s.ldAt, s.ldB = m, n, self.ldA, self.ldAt, self.ldB
+        s.A, s.At, s.b, s.c = ptrs["A"], ptrs["At"], ptrs["b"], ptrs["c"]
+        s.Binv, s.xB, s.basis = ptrs["Binv"], ptrs["xB"], ptrs["basis"]
+        s.var_state = ptrs["var_state"]
+        s.lb = ptrs.get("lb")
+        s.ub = ptrs.get("ub")
+        s.ctrl = ptrs["ctrl"]
+        s.log = ptrs["log"] if self.log_cap > 0 else None
+        s.log_cap = self.log_cap
+        s.workspace, s.workspace_bytes = ptrs["workspace"], ws_bytes
+        if self.naive:
+            s.naive_workspace, s.naive_workspace_bytes = ptrs["naive_workspace"], int(self.lib.lpx_naive_workspace_bytes(m))
+        self._x_ptr, self._cost_ptr = ptrs["x"], ptrs["cost"]
 
     # ------------------------------------------------------------------ control block
     def read_ctrl(self):
+        if self._result is not None:  # downloaded with the result region of the last small solve, still current
+            return self.host_ctrl
         _lib.check(self.lib.lpx_read_ctrl(self.s.ctrl, C.byref(self.host_ctrl), stream_ptr()))
         return self.host_ctrl
 
@@ -110,10 +213,16 @@ class RevisedEngine:
         st = stream_ptr()
         last_refine = None
         last_reinvert = None
+        self._result = None
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         if self.fits_small(kind):
             _lib.check(self.lib.lpx_revised_solve_small(C.byref(self.s), kind, int(maxiters), st))
-            return self.read_ctrl()
+            if self.arena is None:
+                return self.read_ctrl()
+            # arena state: x and cost are assembled right behind the solve (whatever its status: they are functions of
+            # the state) and ONE download brings back the control block and everything solve() returns
+            _lib.check(self.lib.lpx_revised_expand(C.byref(self.s), self._x_ptr, self._cost_ptr, st))
+            return self._fetch_result()
         left = int(maxiters)
         ctrl = None
         first = True
@@ -143,13 +252,31 @@ class RevisedEngine:
             ctrl = self.read_ctrl()
         return ctrl
 
+    def touch(self):
+        """The caller wrote to the state's tensors (or ran liblpx on them) behind the engine's back: drop the host copy."""
+        self._result = None
+
+    def _fetch_result(self):
+        """One D2H copy of the arena's result region -> host views of (ctrl, cost, x, basis, var_state, x_B), kept until
+        the next call that changes the device state."""
+        o0, o1 = self._result_span
+        raw = self.arena[o0:o1].cpu().numpy()
+        res = {}
+        for name, (o, nb, dt, shape) in self._result_offs.items():
+            res[name] = np.ndarray(shape, dtype=dt, buffer=raw, offset=o - o0)
+        C.memmove(C.byref(self.host_ctrl), res["ctrl"].ctypes.data, 128)
+        self._result = res
+        return self.host_ctrl
+
     def enqueue(self, kind, iters):
         """Enqueue iterations without reading the control block (bench / timing windows)."""
+        self._result = None
         _lib.check(self.lib.lpx_revised_iterate(C.byref(self.s), kind, int(iters), stream_ptr()))
 
     def pivot(self, row, col):
         """Caller-chosen basis change; works whatever state the last solve() ended in (kernels gate on RUNNING)."""
         st = stream_ptr()
+        self._result = None
         _lib.check(self.lib.lpx_ctrl_begin_solve(self.s.ctrl, st))
         f = self.lib.lpx_naive_pivot if self.naive else self.lib.lpx_revised_pivot
         _lib.check(f(C.byref(self.s), int(row), int(col), st))
@@ -161,12 +288,14 @@ class RevisedEngine:
         return out.cpu().numpy()
 
     def bounded_update_bfs(self):
+        self._result = None
         _lib.check(self.lib.lpx_bounded_update_bfs(C.byref(self.s), stream_ptr()))
 
     def refine(self, steps=1, update_xB=True):
         """Opt-in: `steps` Newton-Schulz steps on B^-1 in fp64 on the matrix cores (lpx_revised_refine).  Returns
         (max|I - B X| before, after).  Not part of the reference's algorithm; solve() never calls it."""
         torch = self.torch
+        self._result = None
         nbytes = self.lib.lpx_refine_workspace_bytes(self.m)
         work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         resid = torch.zeros(2, dtype=torch.float64, device="cuda")
@@ -180,6 +309,7 @@ class RevisedEngine:
         updates on the matrix cores) and, with update_xB, x_B = B^-1 b.  Raises numpy's LinAlgError for a singular basis,
         as np.linalg.inv does (primal_solvers.py:92-94).  Not part of the reference's revised loop."""
         torch = self.torch
+        self._result = None
         nbytes = self.lib.lpx_invert_workspace_bytes(self.m)
         work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         info = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -191,6 +321,8 @@ class RevisedEngine:
     # ------------------------------------------------------------------ results
     def expand(self):
         """(x, cost) on the host: scatter + dot on the device, one D2H copy (primal_solvers.py:72-79)."""
+        if self._result is not None:
+            return self._result["x"].copy(), np.float64(self._result["cost"][0])
         _lib.check(self.lib.lpx_revised_expand(C.byref(self.s), self.x.data_ptr(), self.cost.data_ptr(), stream_ptr()))
         x = self.x.cpu().numpy()
         return x, np.float64(self.cost.cpu().numpy()[0])
@@ -202,15 +334,21 @@ class RevisedEngine:
         return rc.cpu().numpy()
 
     def host_basis(self):
+        if self._result is not None:
+            return self._result["basis"].copy()
         return self.basis.cpu().numpy()
 
     def host_var_state(self):
+        if self._result is not None:
+            return self._result["var_state"].copy()
         return self.var_state.cpu().numpy()
 
     def host_Binv(self):
         return self.Binv[:, : self.m].cpu().numpy()
 
     def host_xB(self):
+        if self._result is not None:
+            return self._result["xB"].copy()
         return self.xB.cpu().numpy()
 
     def host_log(self, count):

@@ -260,6 +260,7 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
         one_launch = (not warm_start and not self._LOG_CAP and eng.SMALL_SOLVE and m <= eng.SMALL_MAX_ROWS[_lib.KIND_PRIMAL]
                       and lib.lpx_pd_small_lds_bytes(m, n) <= eng.SMALL_LDS_MAX)
         if one_launch and self.counter < maxiters1:
+            eng.touch()
             _lib.check(lib.lpx_ctrl_begin_solve(eng.s.ctrl, st))
             _lib.check(lib.lpx_pd_solve_small(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, int(maxiters1 - self.counter),
                                               int(maxiters2), eng.x.data_ptr(), eng.cost.data_ptr(), st))
@@ -274,6 +275,7 @@ class PrimalDualAlgorithm(DualRevisedSimplexSolver):
             solved = True
         while not one_launch and self.counter < maxiters1:
             self.counter += 1
+            eng.touch()  # this loop writes the engine's tensors itself
             _lib.check(lib.lpx_pd_admissible(C.byref(eng.s), y.data_ptr(), c64.data_ptr(), n, v.data_ptr(), st))  # :405
             if warm_start and self.counter > 1:
                 # keep basis / B^-1 / x_B; artificials that left the basis stay available at their bound, and the
