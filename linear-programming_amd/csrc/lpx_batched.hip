@@ -245,6 +245,46 @@ __device__ __forceinline__ AccT chain_dot_va(const TA *pa, const TB *pb, int64_t
     return acc;
 }
 
+// The same sequential dot product when BOTH operands are contiguous: 16-byte vector loads on both sides (2 doubles / 4
+// floats per instruction) when both are 16-byte aligned -- a chain over a column of A kept TRANSPOSED (LDS copy or the
+// state's At) against y or a row of B^-1 costs 48 load instructions per 64 steps instead of 96-128.  Same order, same bits.
+// DEPTH steps of loads ahead of their fmas: 16 for operands in LDS, 32 when b comes from global memory (one round trip
+// per block).
+template <typename AccT, int DEPTH, typename TA, typename TB>
+__device__ __forceinline__ AccT chain_dot_vv(const TA *pa, const TB *pb, int len)
+{
+    typedef typename ChainVec<TA>::vec veca;
+    typedef typename ChainVec<TB>::vec vecb;
+    constexpr int WA = ChainVec<TA>::W, WB = ChainVec<TB>::W;
+    AccT acc = (AccT)0;
+    int k = 0;
+    if ((((uintptr_t)pa | (uintptr_t)pb) & 15) == 0) {
+        for (; k + DEPTH <= len; k += DEPTH) {
+            veca x[DEPTH / WA];
+            vecb y[DEPTH / WB];
+#pragma unroll
+            for (int u = 0; u < DEPTH / WB; ++u) y[u] = *(const vecb *)(pb + k + WB * u);
+#pragma unroll
+            for (int u = 0; u < DEPTH / WA; ++u) x[u] = *(const veca *)(pa + k + WA * u);
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) acc = fma((AccT)x[u / WA][u % WA], (AccT)y[u / WB][u % WB], acc);
+        }
+    }
+    for (; k + 8 <= len; k += 8) {
+        TA x[8];
+        TB y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = pa[k + u];
+            y[u] = pb[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma((AccT)x[u], (AccT)y[u], acc);
+    }
+    for (; k < len; ++k) acc = fma((AccT)pa[k], (AccT)pb[k], acc);
+    return acc;
+}
+
 // two such dot products against the same global operand in one pass over its loads
 template <typename AccT, int DEPTH, typename TA, typename TB>
 __device__ __forceinline__ void block_dot2_g(const TA *pa1, const TA *pa2, const TB *pb, int64_t sb, int len, AccT &o1, AccT &o2)
@@ -960,14 +1000,19 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
         p += (bytes + 15) / 16 * 16;
         return q;
     };
-    L.ldb = m + 1;
+    // rows of B^-1 start 16-byte aligned (vector loads along a row) an odd number of 16-byte units apart (rows t, t + 1, ...
+    // read by consecutive lanes fall into different banks); down a column consecutive lanes read consecutive words anyway
+    // (the bounded loops read rows 8 bytes at a time: odd stride, conflict-free for that width)
+    const bool bnd = kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED;
+    L.ldb = m + 2 - (m & 1);
+    if (((L.ldb / 2) & 1) == 0) L.ldb += 2;
+    if (bnd) L.ldb = m + 1;
     L.Binv = (double *)take(8 * m * L.ldb);
     L.xB = (double *)take(8 * m);
     L.y = (double *)take(8 * m);
     L.d = (double *)take(8 * m);
     L.e = (double *)take(8 * m);
     L.rowr = (double *)take(8 * m);
-    const bool bnd = kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED;
     L.w = (double *)take(bnd ? 8 * m : 0);
     L.rc = (double *)take(8 * n);
     L.row = (double *)take(kind == LPX_KIND_DUAL ? 8 * n : 0);
@@ -985,14 +1030,27 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
 }
 #define LPX_BLOCK_LDS_MAX (158 * 1024)
 // A beside the state in LDS when both fit: a lone workgroup has nothing to hide an L2 round trip behind, and every chain
-// over A (reduced costs, direction, the bounded solver's b - A_lb lb - A_ub ub) waits for one per 32 steps.  Odd row
-// stride: conflict-free both down a column (lane = column) and along a row (lane = row).
-__host__ __device__ static inline int64_t block_lds_A_ld(int64_t n) { return n | 1; }
-__host__ __device__ static inline int64_t block_lds_A_bytes(int64_t m, int64_t n) { return 4 * m * block_lds_A_ld(n); }
-static inline bool block_A_fits(int64_t state_bytes, int64_t m, int64_t n)
+// over A (reduced costs, direction, the bounded solver's b - A_lb lb - A_ub ub) waits for one per 32 steps.  The copy is
+// TRANSPOSED (column j contiguous, as the state's At): the chains walk DOWN a column, so a lane reads 4 floats per LDS
+// instruction (chain_dot_vv).  Column stride = an odd number of 16-byte units: conflict-free for lane = column, and a
+// row (the bounded solver's sums: lane = row, stride ldt between the steps) has consecutive lanes on consecutive words.
+// The bounded loops keep the copy ROW-major (odd row stride): their longest chain is the n-long sum along a ROW of A
+// (x_B from scratch every iteration, special_solvers.py:169-175), which then reads 4 floats per instruction, and their
+// column chains stay strided.
+__host__ __device__ static inline int64_t block_lds_A_ld(int64_t m)
+{
+    int64_t l = (m + 3) / 4 * 4;
+    return ((l / 4) & 1) ? l : l + 4;
+}
+__host__ __device__ static inline bool block_kind_bounded(int kind) { return kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED; }
+__host__ __device__ static inline int64_t block_lds_A_bytes(int64_t m, int64_t n, int kind)
+{
+    return block_kind_bounded(kind) ? 4 * m * (n | 1) : 4 * n * block_lds_A_ld(m);
+}
+static inline bool block_A_fits(int64_t state_bytes, int64_t m, int64_t n, int kind)
 {
     static const bool on = [] { const char *e = getenv("LPX_SMALL_A_LDS"); return !(e && e[0] == '0'); }();
-    return on && state_bytes + block_lds_A_bytes(m, n) <= LPX_BLOCK_LDS_MAX;
+    return on && state_bytes + block_lds_A_bytes(m, n, kind) <= LPX_BLOCK_LDS_MAX;
 }
 
 // PD: PrimalDualAlgorithm.solve (special_solvers.py:402-447) around the primal loop -- per outer iteration the admissible
@@ -1020,23 +1078,45 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     lpx_ctrl *ctrl = s.ctrl;
     if (ctrl->status != LPX_RUNNING) return;
     const int m = (int)s.m, n = (int)s.n, t = threadIdx.x;
-    int64_t ldA = s.ldA;
     const BlockLds L = block_lds(m, n, PD ? LPX_KIND_PD : KIND, smem);
     const int ldb = (int)L.ldb;
-    const float *A = s.A, *At = s.At;
-    if (a.a_in_lds) {
-        float *Al = (float *)(smem + L.bytes);
-        const int ldl = (int)block_lds_A_ld(n);
-        for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
-            const int i = idx / n, k = idx - i * n;
-            Al[i * ldl + k] = s.A[(int64_t)i * s.ldA + k];
-        }
-        A = Al;
-        ldA = ldl;
-        At = nullptr; // a row of the LDS copy is read as it lies
-    }
     // both bounded-variable loops: the primal one (special_solvers.py:94-343) and the opt-in dual one (lpx.h, LPX_KIND_DUAL_BOUNDED)
     constexpr bool BND = KIND == LPX_KIND_BOUNDED || KIND == LPX_KIND_DUAL_BOUNDED;
+    // BND: A row-major (entry (i, col) at A[i * ldA + col]; At: the state's transposed copy while A is in global memory);
+    // else Ac + col * ldc: column col of A, contiguous (the LDS copy, or the state's transposed copy)
+    const float *A = s.A, *At = s.At, *Ac = s.At;
+    int64_t ldA = s.ldA, ldc = s.ldAt;
+    if (a.a_in_lds) {
+        float *Al = (float *)(smem + L.bytes);
+        if (BND) {
+            const int ldl = n | 1;
+            for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
+                const int i = idx / n, k = idx - i * n;
+                Al[i * ldl + k] = s.A[(int64_t)i * s.ldA + k];
+            }
+            A = Al;
+            ldA = ldl;
+            At = nullptr; // a row of the LDS copy is read as it lies
+        } else {
+            const int ldl = (int)block_lds_A_ld(m);
+            for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
+                const int k = idx / m, i = idx - k * m;
+                Al[k * ldl + i] = s.At[(int64_t)k * s.ldAt + i];
+            }
+            Ac = Al;
+            ldc = ldl;
+        }
+    }
+    const bool lds_a = a.a_in_lds != 0;
+// chain over column col of A against the contiguous vector pa (y, a row of B^-1): k ascending, one fma per step.
+// COLDOT: lane = column.  From global memory the row-major matrix is the coalesced one (64 lanes read 64 consecutive
+// floats per step; the transposed copy would touch 64 cache lines per instruction).  COLDOT_U: the same column in every
+// lane (the direction B^-1 A_j): contiguous from the transposed copy wherever it lies.
+#define COLDOT(AccT, pa, col)                                                                                           \
+    ((BND || !lds_a) ? block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m) : chain_dot_vv<AccT, 16>((pa), Ac + (int64_t)(col) * ldc, m))
+#define COLDOT_U(AccT, pa, col)                                                                                         \
+    (BND ? block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m)                                                             \
+         : (lds_a ? chain_dot_vv<AccT, 16>((pa), Ac + (int64_t)(col) * ldc, m) : chain_dot_vv<AccT, 32>((pa), Ac + (int64_t)(col) * ldc, m)))
     const int n_orig = PD ? (int)a.pd_n_orig : 0;
     int64_t outer = 0;
     int pd_status = LPX_RUNNING;
@@ -1100,7 +1180,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     if (PD) {
         outer += 1;
         for (int col = t; col < n_orig; col += LPX_BLOCK) { // :405-406
-            const double v = block_dot_g<double, 32>(L.yd, 1, A + col, ldA, m);
+            const double v = COLDOT(double, L.yd, col);
             const double cj = a.pd_c64[col];
             L.v[col] = v;
             L.vstate[col] = (fabs(v - cj) <= LPX_ATOL + LPX_RTOL * fabs(cj)) ? LPX_VS_LOWER : LPX_VS_EXCLUDED; // np.isclose
@@ -1170,8 +1250,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             for (int col = t; col < n; col += LPX_BLOCK) {
                 const int vs = L.vstate[col];
                 if (vs == LPX_VS_EXCLUDED) continue; // restricted primal of the primal-dual algorithm
-                double rc = f32 ? (double)(L.c[col] - chain_dot_va<float>(L.y, A + col, ldA, m))
-                                : (double)L.c[col] - chain_dot_va<double>(L.y, A + col, ldA, m);
+                double rc = f32 ? (double)(L.c[col] - COLDOT(float, L.y, col))
+                                : (double)L.c[col] - COLDOT(double, L.y, col);
                 if (vs == LPX_VS_BASIC) rc = 0.0;
                 mn = fmin(mn, rc);
                 if (rc < 0.0 && col < jn) jn = col;
@@ -1191,11 +1271,11 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                 if (vs == LPX_VS_EXCLUDED) continue;
                 double rc, row; // two passes: sharing the loads of A between the two chains measured slower (16 vs 10 us)
                 if (f32) {
-                    rc = (double)(L.c[col] - block_dot_g<float, 32>(L.y, 1, A + col, ldA, m));
-                    row = (double)block_dot_g<float, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                    rc = (double)(L.c[col] - COLDOT(float, L.y, col));
+                    row = (double)COLDOT(float, L.Binv + r * ldb, col);
                 } else {
-                    rc = (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
-                    row = block_dot_g<double, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                    rc = (double)L.c[col] - COLDOT(double, L.y, col);
+                    row = COLDOT(double, L.Binv + r * ldb, col);
                 }
                 if (vs == LPX_VS_BASIC) rc = row = 0.0;
                 const double tj = lpx_dsd(rc, row, f32);
@@ -1217,8 +1297,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             for (int col = t; col < n; col += LPX_BLOCK) {
                 const int vs = L.vstate[col];
                 if (vs != LPX_VS_LOWER && vs != LPX_VS_UPPER) continue;
-                const double rc = (double)L.c[col] - block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
-                const double row = block_dot_g<double, 32>(L.Binv + r * ldb, 1, A + col, ldA, m);
+                const double rc = (double)L.c[col] - COLDOT(double, L.y, col);
+                const double row = COLDOT(double, L.Binv + r * ldb, col);
                 const double alpha = below ? row : -row;
                 if ((vs == LPX_VS_LOWER && alpha < 0.0) || (vs == LPX_VS_UPPER && alpha > 0.0)) {
                     const double tj = (-rc) / alpha;
@@ -1240,8 +1320,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                 double rc = 0.0;
                 if (vs != LPX_VS_BASIC) {
                     float tt;
-                    if (f32) tt = (-L.c[col]) + block_dot_g<float, 32>(L.y, 1, A + col, ldA, m);
-                    else tt = (float)((double)(-L.c[col]) + block_dot_g<double, 32>(L.y, 1, A + col, ldA, m));
+                    if (f32) tt = (-L.c[col]) + COLDOT(float, L.y, col);
+                    else tt = (float)((double)(-L.c[col]) + COLDOT(double, L.y, col));
                     rc = (vs == LPX_VS_UPPER) ? (double)(-tt) : (double)tt;
                 }
                 if (-rc < best || (-rc == best && col < jn)) { best = -rc; jn = col; }
@@ -1270,8 +1350,8 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         // ---- d = B^-1 @ A[:, j] (primal_solvers.py:129): one lane per row, k ascending
         double di = 0.0;
         if (t < m) {
-            di = f32 ? (double)block_dot_g<float, 32>(L.Binv + t * ldb, 1, A + j, ldA, m)
-                     : block_dot_g<double, 32>(L.Binv + t * ldb, 1, A + j, ldA, m);
+            di = f32 ? (double)COLDOT_U(float, L.Binv + t * ldb, j)
+                     : COLDOT_U(double, L.Binv + t * ldb, j);
             L.d[t] = di;
         }
         BS(2)
@@ -1395,7 +1475,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         __syncthreads();
         double th = LPX_INF, um = -LPX_INF;
         for (int col = t; col < n_orig; col += LPX_BLOCK) {
-            const double u = block_dot_g<double, 32>(L.y, 1, A + col, ldA, m);
+            const double u = COLDOT(double, L.y, col);
             if (L.vstate[col] == LPX_VS_EXCLUDED) th = fmin(th, lpx_psd(a.pd_c64[col] - L.v[col], u, false)); // :438-443
             else um = fmax(um, u);
         }
@@ -1458,6 +1538,9 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     }
 }
 
+#undef COLDOT
+#undef COLDOT_U
+
 extern "C" int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind)
 {
     if (m <= 0 || n <= 0) return 0;
@@ -1475,8 +1558,8 @@ static int block_launch(const BlockArgs &a0, int64_t batch, int64_t m, int64_t n
         return LPX_E_SIZE;
     }
     BlockArgs a = a0;
-    a.a_in_lds = block_A_fits(bytes, m, n) ? 1 : 0;
-    if (a.a_in_lds) bytes += block_lds_A_bytes(m, n);
+    a.a_in_lds = block_A_fits(bytes, m, n, kind) ? 1 : 0;
+    if (a.a_in_lds) bytes += block_lds_A_bytes(m, n, kind);
 #define LPX_BLOCK_GO(K)                                                                                                      \
     {                                                                                                                        \
         LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); \
@@ -1508,7 +1591,7 @@ extern "C" int lpx_pd_solve_small(const lpx_revised *s, double *y, const double 
                                   int64_t maxiters2, double *x, double *cost, void *stream)
 {
     LPX_REQUIRE(s != nullptr && s->m > 0 && n_orig > 0 && s->n == n_orig + s->m, "the state must be the restricted primal [A | I]");
-    LPX_REQUIRE(s->A && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
+    LPX_REQUIRE(s->A && s->At && s->b && s->c && s->Binv && s->xB && s->basis && s->var_state && s->ctrl, "null device pointer");
     LPX_REQUIRE(y && c64 && x && cost && maxiters1 >= 0 && maxiters2 >= 0, "bad arguments");
     int64_t bytes = block_lds(s->m, s->n, LPX_KIND_PD, nullptr).bytes;
     if (bytes > LPX_BLOCK_LDS_MAX) {
@@ -1526,8 +1609,8 @@ extern "C" int lpx_pd_solve_small(const lpx_revised *s, double *y, const double 
     a.pd_c64 = c64;
     a.pd_n_orig = n_orig;
     a.pd_maxiters1 = maxiters1;
-    a.a_in_lds = block_A_fits(bytes, s->m, s->n) ? 1 : 0;
-    if (a.a_in_lds) bytes += block_lds_A_bytes(s->m, s->n);
+    a.a_in_lds = block_A_fits(bytes, s->m, s->n, LPX_KIND_PRIMAL) ? 1 : 0;
+    if (a.a_in_lds) bytes += block_lds_A_bytes(s->m, s->n, LPX_KIND_PRIMAL);
     LPX_HIP(hipFuncSetAttribute((const void *)k_block_solve<LPX_KIND_PRIMAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((k_block_solve<LPX_KIND_PRIMAL, true>), dim3(1), dim3(LPX_BLOCK), (size_t)bytes, (hipStream_t)stream, a);
     LPX_LAUNCH_CHECK();
