@@ -1402,7 +1402,41 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                 L.rowr[t] = L.Binv[r * ldb + t];
             }
             __syncthreads();
-            {
+            if (!BND) {
+                // rows of B^-1 are 16-byte aligned here: a lane updates PAIRS of neighbouring columns (one 16-byte load and
+                // store per two elements, the pivot row's pair loaded once when a lane keeps its columns); 8 pairs per lane
+                // at a time, every load before the first store.  A last odd column pairs with the row's padding word.
+                const int P = (m + 1) >> 1, total = m * P;
+                int i = t / P, pp = t - i * P;
+                const int di2 = LPX_BLOCK / P, dp2 = LPX_BLOCK - di2 * P;
+                const bool fixp = dp2 == 0;
+                const d2_t rk0 = *(const d2_t *)(L.rowr + 2 * (pp < P ? pp : 0));
+                for (int idx = t; idx < total; idx += 8 * LPX_BLOCK) {
+                    double ei[8];
+                    d2_t rk[8], bv[8];
+                    int off[8], row[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool ok = idx + u * LPX_BLOCK < total;
+                        row[u] = ok ? i : -1;
+                        off[u] = ok ? i * ldb + 2 * pp : 0;
+                        ei[u] = L.e[ok ? i : 0];
+                        rk[u] = fixp ? rk0 : *(const d2_t *)(L.rowr + (ok ? 2 * pp : 0));
+                        bv[u] = *(const d2_t *)(L.Binv + off[u]);
+                        i += di2; pp += dp2;
+                        if (pp >= P) { pp -= P; i += 1; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (row[u] >= 0) {
+                            d2_t o;
+                            o[0] = (row[u] == r) ? ei[u] * rk[u][0] : fma(ei[u], rk[u][0], bv[u][0]);
+                            o[1] = (row[u] == r) ? ei[u] * rk[u][1] : fma(ei[u], rk[u][1], bv[u][1]);
+                            *(d2_t *)(L.Binv + off[u]) = o;
+                        }
+                    }
+                }
+            } else {
                 // 8 elements per lane at a time, every load before the first store: element by element each step waits
                 // for three dependent LDS round trips (the compiler cannot move a load above the store before it:
                 // 5.9 k cycles per pivot at m = 64, 1.4 k so)
