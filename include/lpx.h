@@ -199,12 +199,17 @@ int lpx_revised_iterate(const lpx_revised *s, int kind, int64_t iters, void *str
  * lpx_ctrl_begin_solve first, as for lpx_revised_iterate).  A single LP of a few hundred rows is launch-bound on the
  * multi-kernel chain (~40 us per iteration whatever its size); here an iteration costs a few microseconds.
  * lpx_revised_small_lds_bytes(m, n, kind) <= 158 KiB says whether a shape fits (m <= 128 at n = 2m), else LPX_E_SIZE.
+ * lpx_revised_small_a_in_lds(m, n, kind) != 0: a copy of A fits beside the state and the kernel makes one (column-major
+ * for the primal / dual loops, row-major for the bounded ones: every chain then reads 16 bytes per LDS instruction); without
+ * it the chains over A wait for global memory once per 32 steps -- the bounded loops, whose x_B is an n-long chain along a
+ * row of A every iteration, are then slower than the multi-kernel chain (43 against 37 us per iteration at 96 x 192).
  * Dot products are accumulated in index order with fma: bit-identical to the oracle's loops.
  * lpx_revised_solve_small_batch: `batch` such states (a DEVICE array of lpx_revised, all m x n), one workgroup each; x
  * (batch x n) and cost (batch) receive the expanded solutions when non-NULL (special_solvers.py:201-206 for bounded).
  * Every state's control block must be RUNNING (lpx_ctrl_begin_solve per LP): a workgroup whose LP is in any other state
  * returns at once and leaves that LP's rows of x and cost UNTOUCHED (stale, not zeroed). */
 int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind);
+int lpx_revised_small_a_in_lds(int64_t m, int64_t n, int kind);
 int lpx_revised_solve_small(const lpx_revised *s, int kind, int64_t maxiters, void *stream);
 int lpx_revised_solve_small_batch(const lpx_revised *dev_states, int64_t batch, int64_t m, int64_t n, int kind,
                                   int64_t maxiters, double *x, double *cost, void *stream);

@@ -72,6 +72,7 @@ _SIGS = {
     "lpx_revised_workspace_bytes": (i64, [i64, i64]),
     "lpx_revised_iterate": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
     "lpx_revised_small_lds_bytes": (i64, [i64, i64, C.c_int]),
+    "lpx_revised_small_a_in_lds": (C.c_int, [i64, i64, C.c_int]),
     "lpx_revised_solve_small": (C.c_int, [C.POINTER(LpxRevised), C.c_int, i64, vp]),
     "lpx_revised_solve_small_batch": (C.c_int, [vp, i64, i64, i64, C.c_int, i64, vp, vp, vp]),
     "lpx_revised_pivot": (C.c_int, [C.POINTER(LpxRevised), i64, i64, vp]),

@@ -285,6 +285,42 @@ __device__ __forceinline__ AccT chain_dot_vv(const TA *pa, const TB *pb, int len
     return acc;
 }
 
+// two sequential dot products against the same contiguous operand b, everything 16-byte aligned and contiguous (the bounded
+// solver's sums along a row of the LDS copy of A): 2 + 2 + 1 load instructions per 4 steps instead of 12
+template <typename AccT, typename TA, typename TB>
+__device__ __forceinline__ void chain_dot2_vv(const TA *pa1, const TA *pa2, const TB *pb, int len, AccT &o1, AccT &o2)
+{
+    typedef typename ChainVec<TA>::vec veca;
+    typedef typename ChainVec<TB>::vec vecb;
+    constexpr int WA = ChainVec<TA>::W, WB = ChainVec<TB>::W;
+    AccT a1 = (AccT)0, a2 = (AccT)0;
+    int k = 0;
+    if ((((uintptr_t)pa1 | (uintptr_t)pa2 | (uintptr_t)pb) & 15) == 0) {
+        for (; k + 16 <= len; k += 16) {
+            veca x1[16 / WA], x2[16 / WA];
+            vecb y[16 / WB];
+#pragma unroll
+            for (int u = 0; u < 16 / WB; ++u) y[u] = *(const vecb *)(pb + k + WB * u);
+#pragma unroll
+            for (int u = 0; u < 16 / WA; ++u) {
+                x1[u] = *(const veca *)(pa1 + k + WA * u);
+                x2[u] = *(const veca *)(pa2 + k + WA * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a1 = fma((AccT)x1[u / WA][u % WA], (AccT)y[u / WB][u % WB], a1);
+                a2 = fma((AccT)x2[u / WA][u % WA], (AccT)y[u / WB][u % WB], a2);
+            }
+        }
+    }
+    for (; k < len; ++k) {
+        a1 = fma((AccT)pa1[k], (AccT)pb[k], a1);
+        a2 = fma((AccT)pa2[k], (AccT)pb[k], a2);
+    }
+    o1 = a1;
+    o2 = a2;
+}
+
 // two such dot products against the same global operand in one pass over its loads
 template <typename AccT, int DEPTH, typename TA, typename TB>
 __device__ __forceinline__ void block_dot2_g(const TA *pa1, const TA *pa2, const TB *pb, int64_t sb, int len, AccT &o1, AccT &o2)
@@ -1002,11 +1038,9 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
     };
     // rows of B^-1 start 16-byte aligned (vector loads along a row) an odd number of 16-byte units apart (rows t, t + 1, ...
     // read by consecutive lanes fall into different banks); down a column consecutive lanes read consecutive words anyway
-    // (the bounded loops read rows 8 bytes at a time: odd stride, conflict-free for that width)
     const bool bnd = kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED;
     L.ldb = m + 2 - (m & 1);
     if (((L.ldb / 2) & 1) == 0) L.ldb += 2;
-    if (bnd) L.ldb = m + 1;
     L.Binv = (double *)take(8 * m * L.ldb);
     L.xB = (double *)take(8 * m);
     L.y = (double *)take(8 * m);
@@ -1034,9 +1068,9 @@ __host__ __device__ static inline BlockLds block_lds(int64_t m, int64_t n, int k
 // TRANSPOSED (column j contiguous, as the state's At): the chains walk DOWN a column, so a lane reads 4 floats per LDS
 // instruction (chain_dot_vv).  Column stride = an odd number of 16-byte units: conflict-free for lane = column, and a
 // row (the bounded solver's sums: lane = row, stride ldt between the steps) has consecutive lanes on consecutive words.
-// The bounded loops keep the copy ROW-major (odd row stride): their longest chain is the n-long sum along a ROW of A
-// (x_B from scratch every iteration, special_solvers.py:169-175), which then reads 4 floats per instruction, and their
-// column chains stay strided.
+// The bounded loops keep the copy ROW-major (rows 16-byte aligned, an odd number of 16-byte units apart): their longest
+// chain is the n-long sum along a ROW of A (x_B from scratch every iteration, special_solvers.py:169-175), which then reads 4
+// floats per instruction (chain_dot2_vv); their column chains stay strided, with the other operand in 16-byte vectors.
 __host__ __device__ static inline int64_t block_lds_A_ld(int64_t m)
 {
     int64_t l = (m + 3) / 4 * 4;
@@ -1045,7 +1079,7 @@ __host__ __device__ static inline int64_t block_lds_A_ld(int64_t m)
 __host__ __device__ static inline bool block_kind_bounded(int kind) { return kind == LPX_KIND_BOUNDED || kind == LPX_KIND_DUAL_BOUNDED; }
 __host__ __device__ static inline int64_t block_lds_A_bytes(int64_t m, int64_t n, int kind)
 {
-    return block_kind_bounded(kind) ? 4 * m * (n | 1) : 4 * n * block_lds_A_ld(m);
+    return block_kind_bounded(kind) ? 4 * m * block_lds_A_ld(n) : 4 * n * block_lds_A_ld(m);
 }
 static inline bool block_A_fits(int64_t state_bytes, int64_t m, int64_t n, int kind)
 {
@@ -1089,7 +1123,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
     if (a.a_in_lds) {
         float *Al = (float *)(smem + L.bytes);
         if (BND) {
-            const int ldl = n | 1;
+            const int ldl = (int)block_lds_A_ld(n);
             for (int idx = t; idx < m * n; idx += LPX_BLOCK) {
                 const int i = idx / n, k = idx - i * n;
                 Al[i * ldl + k] = s.A[(int64_t)i * s.ldA + k];
@@ -1113,9 +1147,10 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
 // floats per step; the transposed copy would touch 64 cache lines per instruction).  COLDOT_U: the same column in every
 // lane (the direction B^-1 A_j): contiguous from the transposed copy wherever it lies.
 #define COLDOT(AccT, pa, col)                                                                                           \
-    ((BND || !lds_a) ? block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m) : chain_dot_vv<AccT, 16>((pa), Ac + (int64_t)(col) * ldc, m))
+    (!lds_a ? block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m)                                                          \
+            : (BND ? chain_dot_va<AccT>((pa), A + (col), ldA, m) : chain_dot_vv<AccT, 16>((pa), Ac + (int64_t)(col) * ldc, m)))
 #define COLDOT_U(AccT, pa, col)                                                                                         \
-    (BND ? block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m)                                                             \
+    (BND ? (lds_a ? chain_dot_va<AccT>((pa), A + (col), ldA, m) : block_dot_g<AccT, 32>((pa), 1, A + (col), ldA, m))      \
          : (lds_a ? chain_dot_vv<AccT, 16>((pa), Ac + (int64_t)(col) * ldc, m) : chain_dot_vv<AccT, 32>((pa), Ac + (int64_t)(col) * ldc, m)))
     const int n_orig = PD ? (int)a.pd_n_orig : 0;
     int64_t outer = 0;
@@ -1165,11 +1200,11 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
         if (t < m) {
             double accl, accu;
             if (At != nullptr) block_dot2_g<double, 32>(L.rc, L.bu, At + t, s.ldAt, n, accl, accu);
-            else block_dot2_g<double, 32>(L.rc, L.bu, A + (int64_t)t * ldA, (int64_t)1, n, accl, accu);
+            else chain_dot2_vv<double>(L.rc, L.bu, A + (int64_t)t * ldA, n, accl, accu);
             L.w[t] = ((double)s.b[t] - accl) - accu;
         }
         __syncthreads();
-        if (t < m) L.xB[t] = batch_dot<double>(L.Binv + t * ldb, 1, L.w, 1, m);
+        if (t < m) L.xB[t] = chain_dot_vv<double, 16>(L.Binv + t * ldb, L.w, m);
         __syncthreads();
     };
     if (BND) bounded_update_bfs();
@@ -1402,7 +1437,7 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                 L.rowr[t] = L.Binv[r * ldb + t];
             }
             __syncthreads();
-            if (!BND) {
+            {
                 // rows of B^-1 are 16-byte aligned here: a lane updates PAIRS of neighbouring columns (one 16-byte load and
                 // store per two elements, the pivot row's pair loaded once when a lane keeps its columns); 8 pairs per lane
                 // at a time, every load before the first store.  A last odd column pairs with the row's padding word.
@@ -1435,30 +1470,6 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
                             *(d2_t *)(L.Binv + off[u]) = o;
                         }
                     }
-                }
-            } else {
-                // 8 elements per lane at a time, every load before the first store: element by element each step waits
-                // for three dependent LDS round trips (the compiler cannot move a load above the store before it:
-                // 5.9 k cycles per pivot at m = 64, 1.4 k so)
-                int i = t / m, k = t - i * m; // incremental (row, col) walk: no division in the loop
-                const int di2 = LPX_BLOCK / m, dk2 = LPX_BLOCK - di2 * m;
-                for (int idx = t; idx < m * m; idx += 8 * LPX_BLOCK) {
-                    double ei[8], rk[8], bv[8];
-                    int off[8], row[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool ok = idx + u * LPX_BLOCK < m * m;
-                        row[u] = ok ? i : -1;
-                        off[u] = ok ? i * ldb + k : 0;
-                        ei[u] = L.e[ok ? i : 0];
-                        rk[u] = L.rowr[ok ? k : 0];
-                        bv[u] = L.Binv[off[u]];
-                        i += di2; k += dk2;
-                        if (k >= m) { k -= m; i += 1; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (row[u] >= 0) L.Binv[off[u]] = (row[u] == r) ? ei[u] * rk[u] : fma(ei[u], rk[u], bv[u]);
                 }
             }
             if (!BND && t < m) L.xB[t] = (t == r) ? L.e[t] * xr : fma(L.e[t], xr, L.xB[t]); // :251-253
@@ -1579,6 +1590,13 @@ extern "C" int64_t lpx_revised_small_lds_bytes(int64_t m, int64_t n, int kind)
 {
     if (m <= 0 || n <= 0) return 0;
     return block_lds(m, n, kind, nullptr).bytes;
+}
+
+extern "C" int lpx_revised_small_a_in_lds(int64_t m, int64_t n, int kind)
+{
+    if (m <= 0 || n <= 0) return 0;
+    const int64_t bytes = block_lds(m, n, kind, nullptr).bytes;
+    return (bytes <= LPX_BLOCK_LDS_MAX && block_A_fits(bytes, m, n, kind)) ? 1 : 0;
 }
 
 static int block_launch(const BlockArgs &a0, int64_t batch, int64_t m, int64_t n, int kind, hipStream_t st)

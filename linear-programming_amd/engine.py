@@ -197,16 +197,23 @@ class RevisedEngine:
     SMALL_SOLVE = os.environ.get("LPX_SMALL_SOLVE", "1") != "0"
     SMALL_LDS_MAX = 158 * 1024
 
-    #: rows up to which the one-launch kernel beats the chain (tools/small_solve_bench.py on MI355X: per iteration at
-    #: m = 64 / 128 -- dual 10 / 21 us against the chain's 28 / 28; bounded, whose x_B is recomputed from scratch through
-    #: an n-long chain every iteration, 30 / 55 us against 42 / 41)
-    SMALL_MAX_ROWS = {_lib.KIND_PRIMAL: 128, _lib.KIND_DUAL: 128, _lib.KIND_BOUNDED: 96,
+    #: rows up to which the one-launch kernel beats the chain (tools/ctor_latency.py, tools/bounded_crossover.py on MI355X,
+    #: per iteration: dual 6.5 / 14 us at m = 64 / 128 against the chain's 28 / 28; bounded, whose x_B is recomputed from
+    #: scratch through an n-long chain along a row of A every iteration, 10 / 12 us at m = 64 / 80 with A beside the state in
+    #: LDS, but 44 / 55 us at m = 96 / 128 where A no longer fits, against the chain's 37 / 35: it takes the kernel only
+    #: while A fits)
+    SMALL_MAX_ROWS = {_lib.KIND_PRIMAL: 128, _lib.KIND_DUAL: 128, _lib.KIND_BOUNDED: 128,
                       _lib.KIND_DUAL_BOUNDED: 4096}  # the opt-in bounded dual loop exists as the one-launch kernel only
 
     def fits_small(self, kind):
         return (self.SMALL_SOLVE and not self.naive and not self.refine_every and not self.reinvert_every
                 and kind in self.SMALL_MAX_ROWS and self.m <= self.SMALL_MAX_ROWS[kind]
-                and self.lib.lpx_revised_small_lds_bytes(self.m, self.n, kind) <= self.SMALL_LDS_MAX)
+                and self.lib.lpx_revised_small_lds_bytes(self.m, self.n, kind) <= self.SMALL_LDS_MAX
+                and (kind != _lib.KIND_BOUNDED or not self.BOUNDED_NEEDS_A_IN_LDS
+                     or bool(self.lib.lpx_revised_small_a_in_lds(self.m, self.n, kind))))
+
+    #: routing rule only (the kernel runs either way; tests switch it off to reach the bounded loops' global-memory path)
+    BOUNDED_NEEDS_A_IN_LDS = True
 
     def run(self, kind, maxiters):
         """One ``solve(maxiters)`` call of the reference: returns the control block after the loop ended."""

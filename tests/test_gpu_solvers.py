@@ -98,6 +98,7 @@ def test_one_launch_small_solve_bit_identical_to_oracle(kind, m, n, seed, monkey
     import linprog_amd.engine as engine
 
     monkeypatch.setattr(engine.RevisedEngine, "SMALL_MAX_ROWS", {0: 4096, 1: 4096, 2: 4096})  # every shape that fits LDS
+    monkeypatch.setattr(engine.RevisedEngine, "BOUNDED_NEEDS_A_IN_LDS", False)  # 128 x 256: the bounded loops with A in HBM
     if kind == "bounded":
         args = gen.gen_box(m, n, seed)
         s = logged(BoundedVariablePrimalSimplexSolver)(*args)
