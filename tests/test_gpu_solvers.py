@@ -632,3 +632,42 @@ def test_bounded_variable_dual_simplex_errors():
     args = gen.gen_box_dual(170, 340, 0)
     with pytest.raises(ValueError):
         BoundedVariableDualSimplexSolver(*args)
+
+
+@pytest.mark.parametrize("kind,m,n,seed", [("primal", 24, 60, 1), ("dual", 64, 128, 2), ("bounded", 40, 90, 3), ("primal", 150, 320, 4)])
+def test_arena_state_equals_a_tensor_per_array(kind, m, n, seed, monkeypatch):
+    """RevisedEngine keeps a small state in ONE device allocation (one upload; x, cost, basis, control block back in one
+    download after a one-launch solve).  Same results, bit for bit, as the state with a tensor per array -- piecewise
+    solves, a caller's pivot() in between (the host copy of the results must not outlive it), the attributes other code
+    reads."""
+    import linprog_amd.engine as engine
+    from linprog_amd.dual_solvers import DualRevisedSimplexSolver
+    from linprog_amd.primal_solvers import PrimalRevisedSimplexSolver
+    from linprog_amd.special_solvers import BoundedVariablePrimalSimplexSolver
+
+    cls = {"primal": PrimalRevisedSimplexSolver, "dual": DualRevisedSimplexSolver, "bounded": BoundedVariablePrimalSimplexSolver}[kind]
+    args = {"primal": gen.gen_primal, "dual": gen.gen_dual, "bounded": gen.gen_box}[kind](m, n, seed)
+    a = logged(cls)(*args)
+    monkeypatch.setattr(engine.RevisedEngine, "ARENA_MAX", -1)
+    t = logged(cls)(*args)
+    assert a._engine.arena is not None and t._engine.arena is None
+    for k in (1, 3, 100000):
+        ra, rt = a.solve(k), t.solve(k)
+        assert ra.iters == rt.iters and ra.optimum == rt.optimum
+        assert np.array_equal(ra.x, rt.x) and ra.cost == rt.cost and np.array_equal(ra.basis, rt.basis)
+        assert a.pivot_log().tolist() == t.pivot_log().tolist()
+        assert np.array_equal(a.bfs, t.bfs) and np.array_equal(a.inv_basis_matrix, t.inv_basis_matrix)
+        if kind == "bounded":
+            assert np.array_equal(a.lb_nonbasic_vars, t.lb_nonbasic_vars) and np.array_equal(a.ub_nonbasic_vars, t.ub_nonbasic_vars)
+        if kind == "primal" and k == 1:
+            # a basis change behind solve()'s back: entering = the next pivot the loop itself would take (always legal)
+            probe = logged(cls)(*args)
+            probe.solve(2)
+            row, col, _ = probe.pivot_log().tolist()[1]
+            a.pivot(row, col)
+            t.pivot(row, col)
+            assert np.array_equal(a.basis, t.basis) and a.basis[row] == col
+            assert np.array_equal(a.bfs, t.bfs)
+            xa, xt = a._get_bfs_expanded(), t._get_bfs_expanded()
+            assert np.array_equal(xa, xt) and xa[col] == a.bfs[row]
+    assert ra.optimum
