@@ -236,6 +236,44 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
                      "gate": "same run, state carried on from the timed window: pivot count and RUNNING status checked, the "
                              "log's prefix against the oracle (cpu_baseline.parity), x_B >= 0 and the cost below the timed "
                              "window's afterwards"}
+    # The per-pivot form of the same update (SURVEY 8(d)'s figure, north_star's ">= 70 % of peak HBM bandwidth on the pivot
+    # update"): a few more pivots of the SAME run with the deferred chain switched off, i.e. one streaming rank-1 update of
+    # the whole tableau per pivot (k_rank1), timed with HIP events like the pass above.  Same arithmetic, same pivots.
+    eager = None
+    if blocks and kb and group is None and os.environ.get("LPX_BENCH_EAGER", "1") != "0":
+        E_piv = 12
+        knobs = {"LPX_TABLEAU_BLOCK_MIN_MB": str(1 << 30),  # liblpx reads these per call: no tableau is that large,
+                 "LPX_TABLEAU_FUSED": "0"}                  # and no two-buffer chain: the plain column -> prepare -> K1 loop
+        saved = {k: os.environ.get(k) for k in knobs}
+        os.environ.update(knobs)
+        try:
+            if int(lib.lpx_tableau_block_size(C.byref(eng.s))) == 0 and int(lib.lpx_tableau_chain_kind(C.byref(eng.s))) == _lib.CHAIN_EAGER:
+                eng.enqueue(2)  # the chain's own first launches (pricing scan of a fresh call)
+                barrier()
+                _lib.check(lib.lpx_profile_k1(1))
+                t2 = time.perf_counter()
+                eng.enqueue(E_piv)
+                barrier()
+                de = time.perf_counter() - t2
+                e_ms, e_n = C.c_double(), C.c_int64()
+                _lib.check(lib.lpx_profile_k1_read(C.byref(e_ms), C.byref(e_n)))
+                _lib.check(lib.lpx_profile_k1(0))
+                extra += 2 + E_piv
+                if e_n.value > 0:
+                    e_avg = e_ms.value / 1e3 / e_n.value
+                    eb = 16.0 * (m + 1) * (ncarry + 1)
+                    eager = {"kernel": "k_rank1<tableau>: ONE rank-1 update of the whole tableau per pivot (the deferred chain switched "
+                                       "off for these pivots; same run, same arithmetic)",
+                             "pivots": E_piv, "pivots_per_s": E_piv / de, "launches": e_n.value, "avg_launch_ms": e_avg * 1e3,
+                             "bytes_per_launch": eb, "achieved": eb / e_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": eb / e_avg / 1e9 / HBM_PEAK_GBS,
+                             "note": "16 B per element and pivot: SURVEY 8(d)'s algorithmic bytes for the layout that ran"}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     ctrl = eng.read_ctrl()
     pivots_done = int(ctrl.pivots)
     if pivots_done != W_piv + K_piv + extra or ctrl.status != _lib.RUNNING:
@@ -313,6 +351,8 @@ def bench_tableau(args, rank, world, group, m, n, K, W, blocks=False):
     }
     if sustained is not None:
         out["sustained"] = sustained
+    if eager is not None:
+        out["roofline"]["eager_update"] = eager
     if kb:
         r = out["roofline"]
         del r["whole_pivot_GBs"]
