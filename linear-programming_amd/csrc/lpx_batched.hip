@@ -1304,8 +1304,19 @@ __global__ __launch_bounds__(LPX_BLOCK) void k_block_solve(BlockArgs a)
             for (int col = t; col < n; col += LPX_BLOCK) {
                 const int vs = L.vstate[col];
                 if (vs == LPX_VS_EXCLUDED) continue;
-                double rc, row; // two passes: sharing the loads of A between the two chains measured slower (16 vs 10 us)
-                if (f32) {
+                double rc, row;
+                if (lds_a) { // both chains in one pass over the column's 16-byte loads, their fmas interleaved (same order each)
+                    if (f32) {
+                        float z, rw;
+                        chain_dot2_vv<float>(L.y, L.Binv + r * ldb, Ac + (int64_t)col * ldc, m, z, rw);
+                        rc = (double)(L.c[col] - z);
+                        row = (double)rw;
+                    } else {
+                        double z;
+                        chain_dot2_vv<double>(L.y, L.Binv + r * ldb, Ac + (int64_t)col * ldc, m, z, row);
+                        rc = (double)L.c[col] - z;
+                    }
+                } else if (f32) { // from global memory two passes: sharing the loads there measured slower (16 vs 10 us)
                     rc = (double)(L.c[col] - COLDOT(float, L.y, col));
                     row = (double)COLDOT(float, L.Binv + r * ldb, col);
                 } else {
