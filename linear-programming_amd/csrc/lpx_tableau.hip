@@ -1412,8 +1412,10 @@ static void tb_flush_from(const lpx_tableau *s, const TbWs &h, const double *src
     const int nt = lpx_env_int("LPX_RANK1_NT", (8 * f.rows * f.cols > ((int64_t)192 << 20)) ? 1 : 0) ? 1 : 0;
     int64_t rpb = lpx_env_int("LPX_TB_ROWS", 0);
     if (rpb <= 0) {
-        // workgroups to aim for: the condensed layout's blocks of 32 run 4 workgroups per CU (lpx_tb_flush32.hip), the rest 2
-        int64_t nbands = lpx_cdiv(lpx_env_int("LPX_TB_WGS", (KB == 32 && nt && f.cond) ? 20480 : 5120), nstrips);
+        // workgroups to aim for: the condensed layout's blocks of 32 run 4 workgroups per CU (lpx_tb_flush32.hip), the rest 2.
+        // 10240 (bands of ~320 rows at 20001 x 20001): as fast as 20480 (profiles/r03_pass_wgs_sweep.log) with half the
+        // refills of the pivot-row strips; fewer, taller workgroups lose
+        int64_t nbands = lpx_cdiv(lpx_env_int("LPX_TB_WGS", (KB == 32 && nt && f.cond) ? 10240 : 5120), nstrips);
         if (nbands < 1) nbands = 1;
         rpb = lpx_roundup(lpx_cdiv(f.rows, nbands), 32);
     }
