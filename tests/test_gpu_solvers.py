@@ -671,3 +671,27 @@ def test_arena_state_equals_a_tensor_per_array(kind, m, n, seed, monkeypatch):
             xa, xt = a._get_bfs_expanded(), t._get_bfs_expanded()
             assert np.array_equal(xa, xt) and xa[col] == a.bfs[row]
     assert ra.optimum
+
+
+def test_bounded_solver_takes_the_one_launch_kernel_only_while_A_fits_in_lds():
+    """Routing rule of RevisedEngine.fits_small for the bounded loops (lpx_revised_small_a_in_lds): 80 x 160 keeps A beside
+    the state in LDS and runs as one launch, 96 x 192 does not and takes the multi-kernel chain; both take the oracle's
+    pivots (the kernel itself is bit-identical either way: test_one_launch_small_solve_bit_identical_to_oracle)."""
+    from linprog_amd import _lib
+    from linprog_amd.special_solvers import BoundedVariablePrimalSimplexSolver
+    from oracle import oracle as O
+
+    lib = _lib.load()
+    assert lib.lpx_revised_small_a_in_lds(80, 160, _lib.KIND_BOUNDED) == 1
+    assert lib.lpx_revised_small_a_in_lds(96, 192, _lib.KIND_BOUNDED) == 0
+    assert lib.lpx_revised_small_a_in_lds(64, 128, _lib.KIND_PRIMAL) == 1 and lib.lpx_revised_small_a_in_lds(128, 256, _lib.KIND_PRIMAL) == 0
+    assert lib.lpx_revised_small_a_in_lds(0, 5, _lib.KIND_PRIMAL) == 0
+    for m, one_launch in ((80, True), (96, False)):
+        args = gen.gen_box(m, 2 * m, 7)
+        s = logged(BoundedVariablePrimalSimplexSolver)(*args)
+        assert s._engine.fits_small(_lib.KIND_BOUNDED) is one_launch
+        res, want = s.solve(100000), O.OracleBounded(*args).solve(100000)
+        assert res.optimum and res.iters == want.iters
+        assert s.pivot_log().tolist() == want.log.tolist()
+        assert_close(res.x, want.x, "x")
+        assert_close(res.cost, want.cost, "cost")
